@@ -1,0 +1,227 @@
+/* slam_amd.h -- C ABI of libslam_amd.so: the MI355X (gfx950) implementation of the stereo-trajectory
+ * hot path of maoratar1/SLAM (utils/utills.py).
+ *
+ * The reference is pure Python and has no FFI layer; its boundary for this path is the set of
+ * module-level functions of utils/utills.py.  Each entry point below names the reference
+ * function(s) whose arithmetic it replaces (paths relative to the reference root).
+ * slam_amd/utills.py binds them (ctypes) behind the reference's own signatures; INTEGRATION.md
+ * shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative SLAM_E_* code; slam_last_error_string()
+ *     describes the last failure on the calling thread.  No exception crosses the ABI.
+ *   - `d_` pointers are device memory owned by the caller; `h_` pointers are host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     asynchronous on that stream unless stated otherwise.  No entry point allocates or frees
+ *     device memory: scratch comes from the caller-provided workspace.
+ *   - descriptors are rows of SLAM_DESC_STRIDE (64) bytes: the 61 bytes of an AKAZE MLDB descriptor
+ *     followed by zero padding (zero padding is distance-neutral).
+ *   - a packed match key is (distance << 20) | index, 0xFFFFFFFF = no match.
+ */
+#ifndef SLAM_AMD_H
+#define SLAM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM_DESC_STRIDE 64
+#define SLAM_KEY_SHIFT 20
+#define SLAM_KEY_NONE 0xFFFFFFFFu
+#define SLAM_MAX_ROWS (1 << SLAM_KEY_SHIFT)
+
+/* cv2 enum values the reference passes (utils/utills.py:24) */
+#define SLAM_NORM_HAMMING 6
+#define SLAM_NORM_HAMMING2 7
+
+/* matcher modes: utils/utills.py:108-110 (cross-check brute force) and :112-119 (kNN, k = 2) */
+#define SLAM_MATCH_CROSSCHECK 0
+#define SLAM_MATCH_KNN2 1
+
+#define SLAM_OK 0
+#define SLAM_E_INVALID (-1)     /* bad argument (null pointer, size out of range) */
+#define SLAM_E_WORKSPACE (-2)   /* workspace too small */
+#define SLAM_E_HIP (-3)         /* a HIP runtime call failed */
+#define SLAM_E_EMPTY (-4)       /* empty tracked set: the reference raises ValueError (utills.py:502) */
+
+const char *slam_version(void);
+const char *slam_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Matching.  Replaces cv2.BFMatcher(NORM_HAMMING2, crossCheck=True).match (utils/utills.py:57-70,
+ * :105-110) and cv2.BFMatcher(...).knnMatch(.., 2) (utils/utills.py:92-102).
+ *
+ * SLAM_MATCH_CROSSCHECK: d_key1[i] = packed (distance, train row) matched to query row i under
+ *   OpenCV's cross-check rule, or SLAM_KEY_NONE; d_key2 is not written (may be NULL).
+ * SLAM_MATCH_KNN2: d_key1[i] / d_key2[i] = nearest / second nearest train row of query i (ties:
+ *   lower train index first).
+ * d_query / d_train: [n][64] bytes, 16-byte aligned.  n_query, n_train < SLAM_MAX_ROWS.
+ * Workspace: slam_match_workspace_bytes(n_query, n_train) bytes of device memory.
+ */
+size_t slam_match_workspace_bytes(int n_query, int n_train);
+int slam_match_hamming(const uint8_t *d_query, int n_query, const uint8_t *d_train, int n_train, int norm,
+                       int mode, uint32_t *d_key1, uint32_t *d_key2, void *d_workspace, size_t workspace_bytes,
+                       void *stream);
+
+/* Batched form: one launch for many image pairs.  Image k holds h/d_count[k] rows at
+ * d_desc + k * n_max * 64.  Problem p matches query image prob_query[p] against train image
+ * prob_train[p]; results go to d_key1 + p * n_max (and d_key2 + p * n_max for KNN2).
+ * d_prob_query / d_prob_train / d_count are device int32 arrays.  No workspace. */
+int slam_match_hamming_batched(const uint8_t *d_desc, const int32_t *d_count, int n_max, const int32_t *d_prob_query,
+                               const int32_t *d_prob_train, int n_prob, int norm, int mode, uint32_t *d_key1,
+                               uint32_t *d_key2, void *stream);
+
+/* Unpacks keys into the (trainIdx, distance) pairs of cv2.DMatch; -1 / INT32_MAX where there is no match. */
+int slam_unpack_keys(const uint32_t *d_key, int n, int32_t *d_index, int32_t *d_distance, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Rectified-stereo rejection + 4-view join + coordinate gather.  Replaces
+ * rectified_stereo_pattern_rej (utils/utills.py:168-183), create_rec_dic (:423-435),
+ * find_kpts_in_all_4_rec (:438-471), tracking_4images (:945-960) and the gathers of
+ * get_feature_obj / get_features_*_coor (:963-997), batched over frame pairs.
+ *
+ * Frame f owns images 2f (left) and 2f+1 (right); d_xy is [n_img][n_max][2] float32.
+ * d_stereo_key: [n_frames][n_max] cross-check keys, query = left image, train = right image.
+ * d_temporal_key: [n_pairs][n_max] cross-check keys, query = left of pair_f0[p], train = left of pair_f1[p].
+ * Outputs per pair p (rows beyond d_tracked_count[p] are untouched):
+ *   d_tracked_count[p]             number T of correspondences seen in all four images
+ *   d_tracked_kp[p][n_max][4]      key-point indices (left0, right0, left1, right1), ascending left0
+ *   d_xy0[p][n_max][4]             float32 (xL0, yL0, xR0, yR0)
+ *   d_xy1[p][n_max][4]             float32 (xL1, yL1, xR1, yR1)
+ * rec_err: REC_ERR (utils/utills.py:41), inclusive, compared in float64.
+ */
+int slam_rect_filter_join(const float *d_xy, const int32_t *d_count, int n_max, const uint32_t *d_stereo_key,
+                          const uint32_t *d_temporal_key, const int32_t *d_pair_f0, const int32_t *d_pair_f1,
+                          int n_pairs, double rec_err, int32_t *d_tracked_count, int32_t *d_tracked_kp,
+                          float *d_xy0, float *d_xy1, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Triangulation.  Replaces linear_least_square + triangulate (utils/utills.py:220-255): per
+ * correspondence the 4x4 DLT matrix, its right singular vector of least singular value,
+ * dehomogenised.  h_P / h_Q: row-major 3x4 float64 projection matrices (K@M1, K@M2).
+ * Batched: segment s holds d_count[s] points at d_xy + s*seg_stride*4 (float32 xL,yL,xR,yR);
+ * output d_X + s*seg_stride*3 (float64).  d_count == NULL means one segment of seg_stride points.
+ */
+int slam_triangulate(const double *h_P, const double *h_Q, const float *d_xy, const int32_t *d_count, int n_seg,
+                     int seg_stride, double *d_X, void *stream);
+/* float64 coordinates, single segment (the drop-in `triangulate` receives float64 arrays) */
+int slam_triangulate_f64(const double *h_P, const double *h_Q, const double *d_xy_l, const double *d_xy_r, int n,
+                         double *d_X, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Minimal-sample index streams.  Reproduces np.random.seed(seed); np.random.randint(0, n, 4)
+ * repeated (utils/utills.py:502): MT19937 + numpy's masked rejection.
+ * slam_mt19937_words: host; fills h_words[n_words] with the raw 32-bit outputs after seeding.
+ * slam_randint_host: host; h_out[n_out] = the first n_out values of randint(0, bound, ...);
+ *   returns the number of raw words consumed (>= 0) or a negative error.
+ */
+int slam_mt19937_words(uint32_t seed, uint32_t *h_words, int n_words);
+long slam_randint_host(uint32_t seed, uint32_t bound, int32_t *h_out, long n_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * PnP hypotheses.  Replaces pnp(..., cv2.SOLVEPNP_AP3P) + rodriguez_to_mat (utils/utills.py:574-596,
+ * call site :503): Ke & Roumeliotis AP3P on the first three sample points, the fourth picks the root.
+ * Segment s (a frame pair) has d_count[s] points: d_X + s*seg_stride*3 (float64) and
+ * d_xy1 + s*seg_stride*4 (float32 xL1,yL1,xR1,yR1; only the left pair is used).  d_sample holds
+ * n_hyp x 4 point indices per segment ([n_seg][n_hyp][4] int32).  Outputs [n_seg][n_hyp]:
+ *   d_pose[..][12]  row-major 3x4 [R|t] (NaN-filled where the sample is degenerate)
+ *   d_status[..]    1 = pose returned, 0 = solver found no root (the reference's `continue`, :506-507)
+ * h_K: row-major 3x3 calibration.
+ */
+int slam_p3p_hypotheses(const double *h_K, const double *d_X, const float *d_xy1, const int32_t *d_count, int n_seg,
+                        int seg_stride, const int32_t *d_sample, int n_hyp, double *d_pose, uint8_t *d_status,
+                        void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Consensus scoring.  Replaces consensus_match -> compose_transformations, find_supporters_4_frame,
+ * project, check_projection, compute_square_dist (utils/utills.py:533-545, :659-736): for every
+ * hypothesis, project all points of its segment into left1 and right1 and test the un-squared
+ * pixel distance against thr = acc**2 (inclusive) in both.
+ * d_pose: [n_seg][n_hyp][12]; d_status as above (status 0 hypotheses are skipped, count 0).
+ * d_inlier_count: [n_seg][n_hyp] int32.  d_mask (optional, may be NULL): [n_seg][n_hyp][seg_stride/64]
+ * uint64 bit masks, bit i%64 of word i/64 = point i supports.  seg_stride must be a multiple of 64.
+ * h_K 3x3, h_M2 3x4 row-major float64.
+ */
+int slam_score_hypotheses(const double *h_K, const double *h_M2, const double *d_X, const float *d_xy1,
+                          const int32_t *d_count, int n_seg, int seg_stride, const double *d_pose,
+                          const uint8_t *d_status, int n_hyp, double thr, int32_t *d_inlier_count, uint64_t *d_mask,
+                          void *stream);
+/* float64 observations, one segment, one pose (drop-in `consensus_match`) */
+int slam_consensus_match_f64(const double *h_K, const double *h_M2, const double *h_pose, const double *d_X,
+                             const double *d_left1, const double *d_right1, int n, double thr, uint8_t *d_mask,
+                             void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Refit.  Replaces extra_refine -> pnp(..., cv2.SOLVEPNP_ITERATIVE) (utils/utills.py:548-571):
+ * Levenberg-Marquardt on the left-image reprojection error over the supporters, started from the
+ * winning hypothesis.  Per segment: d_mask_words [seg_stride/64] uint64, d_pose0 [12] -> d_pose [12];
+ * d_status: 1 = refit done, 0 = fewer than 6 supporters (pose None, :558-559), NaN-filled pose.
+ */
+int slam_refit_pnp(const double *h_K, const double *d_X, const float *d_xy1, const int32_t *d_count, int n_seg,
+                   int seg_stride, const uint64_t *d_mask_words, const double *d_pose0, double *d_pose,
+                   uint8_t *d_status, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole shard.  Replaces the body of find_features_in_consecutive_frames_whole_movie
+ * (utils/utills.py:834-873) / find_loop_cand_by_consensus (:1118-1146) minus detection: stereo match
+ * of every frame, then per frame pair temporal match, join, triangulation, adaptive PnP-RANSAC
+ * (online_est_pnp_ransac, :474-530, replayed on the host over batched device results) and refit.
+ * Synchronous: returns when the host outputs are filled.
+ */
+typedef struct SlamTrackConfig {
+    double K[9];             /* calibration, row-major */
+    double M1[12];           /* left extrinsic [I|0] */
+    double M2[12];           /* right-to-left extrinsic */
+    double rec_err;          /* REC_ERR = 2 */
+    double acc;              /* SUPP_ERR = 2; the test is distance <= acc*acc */
+    double prob;             /* 0.9999 */
+    double max_iterations;   /* 1e3 */
+    int32_t fixed_iterations;/* > 0: ignore the adaptive stop and run exactly this many counted iterations */
+    int32_t max_draws;       /* bound on draws incl. failed ones (the reference is unbounded); 0 = 64 * max_iterations */
+    int32_t norm;            /* SLAM_NORM_HAMMING2 */
+    int32_t first_chunk;     /* hypotheses evaluated speculatively in round 1 (0 = 64) */
+} SlamTrackConfig;
+
+typedef struct SlamTrackIO {
+    /* device inputs */
+    const uint8_t *d_desc;   /* [2*n_frames][n_max][64]: image 2f = left of frame f, 2f+1 = right */
+    const float *d_xy;       /* [2*n_frames][n_max][2] */
+    const int32_t *d_count;  /* [2*n_frames] */
+    int32_t n_frames, n_max;
+    /* host inputs */
+    const int32_t *h_pair_f0, *h_pair_f1; /* [n_pairs] frame indices (consecutive: f, f+1) */
+    const uint32_t *h_pair_seed;          /* [n_pairs] np.random.seed value in force before each pair's RANSAC */
+    int32_t n_pairs;
+    /* device outputs (caller-allocated) */
+    int32_t *d_tracked_kp;   /* [n_pairs][n_max][4] */
+    /* host outputs (caller-allocated) */
+    double *h_pose;          /* [n_pairs][12]; NaN where the reference returns None */
+    int32_t *h_stats;        /* [n_pairs][8]: tracked T, supporters, iterations, draws, best draw, status, stereo0 matches, temporal matches */
+    uint64_t *h_mask;        /* [n_pairs][n_max/64] supporter bit masks (pre-refit, as the reference returns) */
+    /* scratch */
+    void *d_workspace; size_t d_workspace_bytes;
+    void *h_workspace; size_t h_workspace_bytes; /* pinned host memory */
+} SlamTrackIO;
+
+/* status bits in h_stats[p][5] */
+#define SLAM_PAIR_OK 1          /* refit pose returned */
+#define SLAM_PAIR_EMPTY 2       /* T == 0: the reference raises ValueError */
+#define SLAM_PAIR_FEW 4         /* < 6 supporters: pose None */
+#define SLAM_PAIR_DRAW_CAP 8    /* max_draws reached before the loop condition ended */
+
+size_t slam_track_device_workspace_bytes(int n_frames, int n_pairs, int n_max, const SlamTrackConfig *cfg);
+size_t slam_track_host_workspace_bytes(int n_frames, int n_pairs, int n_max, const SlamTrackConfig *cfg);
+int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *io, void *stream);
+
+/* per-stage device times (ms) of the last slam_track_pairs call on this thread, measured with HIP events on
+ * `stream`: [0] match, [1] join, [2] triangulate, [3] hypotheses+score (all rounds), [4] mask+refit,
+ * [5] whole call wall (host clock), [6] host replay + RNG (host clock), [7] match kernel launches */
+int slam_track_last_timing(double *h_ms8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

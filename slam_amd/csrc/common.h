@@ -1,0 +1,35 @@
+// Shared host-side helpers of libslam_amd.so (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/slam_amd.h"
+
+void slam_set_error(const char *fmt, ...);
+
+#define SLAM_HIP_CHECK(expr)                                                                          \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            slam_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SLAM_E_HIP;                                                                        \
+        }                                                                                             \
+    } while (0)
+
+#define SLAM_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            slam_set_error(__VA_ARGS__);   \
+            return SLAM_E_INVALID;         \
+        }                                  \
+    } while (0)
+
+static inline int slam_div_up(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t slam_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// 3x4 / 3x3 matrices handed to kernels by value
+struct Mat34 { double m[12]; };
+struct Mat33 { double m[9]; };

@@ -1,0 +1,32 @@
+// Internal launchers shared between the per-stage C ABI (one file per stage) and the shard pipeline.
+#pragma once
+#include "common.h"
+
+int slam_launch_rect_join(const float *d_xy, const int32_t *d_count, int n_max, const uint32_t *d_stereo_key,
+                          const uint32_t *d_temporal_key, const int32_t *d_pair_f0, const int32_t *d_pair_f1,
+                          int n_pairs, double rec_err, int32_t *d_tracked_count, int32_t *d_tracked_kp, float *d_xy0,
+                          float *d_xy1, int32_t *d_aux, hipStream_t st);
+
+// Maps raw MT19937 words to np.random.randint(0, count[s], ...) values by numpy's masked rejection.
+// d_words: [n_seg][words_per_seg]; d_seg_of: optional indirection (segment index per row of d_words/d_sample,
+// NULL = identity); writes d_sample[row][n_draw*4] and d_produced[row] = number of complete 4-index draws.
+int slam_launch_map_samples(const uint32_t *d_words, int words_per_seg, const int32_t *d_count,
+                            const int32_t *d_seg_of, int n_rows, int n_draw, int32_t *d_sample, int32_t *d_produced,
+                            hipStream_t st);
+
+// Hypotheses + scoring with an optional row -> segment indirection (rows = active pairs of a RANSAC round).
+int slam_launch_p3p(const Mat33 &K, const double *d_X, const float *d_xy1, const int32_t *d_count,
+                    const int32_t *d_seg_of, int n_rows, int seg_stride, const int32_t *d_sample, int sample_stride,
+                    int draw0, int n_hyp, double *d_pose, uint8_t *d_status, hipStream_t st);
+int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const float *d_xy1, const int32_t *d_count,
+                      const int32_t *d_seg_of, int n_rows, int seg_stride, const double *d_pose,
+                      const uint8_t *d_status, int n_hyp, double thr, int32_t *d_inlier_count, uint64_t *d_mask,
+                      hipStream_t st);
+int slam_launch_refit(const Mat33 &K, const double *d_X, const float *d_xy1, const int32_t *d_count, int n_seg,
+                      int seg_stride, const uint64_t *d_mask_words, const double *d_pose0, double *d_pose,
+                      uint8_t *d_status, hipStream_t st);
+int slam_launch_triangulate(const Mat34 &P, const Mat34 &Q, const float *d_xy, const int32_t *d_count, int n_seg,
+                            int seg_stride, double *d_X, hipStream_t st);
+
+// host RNG (ransac_host.cpp)
+void slam_mt_seed_words(uint32_t seed, uint32_t *out, int n_words);

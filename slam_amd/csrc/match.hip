@@ -1,0 +1,348 @@
+// All-pairs binary-descriptor matching for gfx950.
+//
+// Replaces cv2.BFMatcher(NORM_HAMMING2, crossCheck=True).match and .knnMatch(k=2) as called from
+// utils/utills.py:57-70, :92-102, :105-119 of the reference.
+//
+// Shape of the work: integer VALU (xor / or / popcount), not a GEMM and not HBM bound
+// (2000 x 2000 rows x 64 B = 256 KB in, 35 lane-ops per row pair).  Mapping:
+//   - every lane owns ROWS "A" rows in registers (64 VGPRs), pre-transformed so that a
+//     NORM_HAMMING2 distance over 64 bytes costs 8 x (xor, xor, or, popcount-accumulate):
+//     each dword pair (w0, w1) is re-packed into E = even bits of w0 | even bits of w1 << 1 and
+//     O = odd bits of w0 >> 1 | odd bits of w1, so a 2-bit cell differs iff (Ea^Eb)|(Oa^Ob) has
+//     its bit set (16 + 16 cells per dword pair, one popcount each).
+//   - "B" rows are staged through LDS in tiles (double buffered, transformed on the way in) and
+//     read back with ds_read_b128 broadcasts: one LDS read feeds ROWS x 64 distance updates.
+//   - running top-2 per A row as packed keys (distance << 20 | B row): one v_min_u32 and one
+//     v_med3_u32 per pair; lowest index wins ties because the index is in the key's low bits.
+//   - cross-check (OpenCV batchDistance(crosscheck=true)): A = train rows; the nearest query of
+//     every train row is scattered with atomicMin on key (distance << 20 | train row) into the
+//     query's slot.  min is order independent, so the result is deterministic.
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS = 4;            // A rows per lane
+constexpr int BLOCK = 128;         // threads per workgroup (2 waves)
+constexpr int TILE_A = ROWS * BLOCK;
+constexpr int TILE_B = 128;        // B rows per LDS tile (8 KB)
+constexpr unsigned NONE = SLAM_KEY_NONE;
+
+struct MatchBatch {
+    const uint4 *desc;        // batched: image k at desc + k * n_max * 4
+    const int *count;         // batched: rows per image
+    const int *prob_a;        // batched: A image per problem
+    const int *prob_b;        // batched: B image per problem
+    const uint4 *a_ptr;       // single problem
+    const uint4 *b_ptr;
+    int na, nb;               // single problem sizes
+    int n_max;                // rows per image slot
+    unsigned *out1, *out2;    // per problem stride out_stride (top-1 / top-2 keys, or cross-check slots)
+    int out_stride;
+    int tiles_per_prob;       // A tiles per problem
+    int nsplit;               // B splits (blockIdx.y)
+    int n_prob;
+};
+
+// (x, y, z, w) -> (E(x,y), E(z,w), O(x,y), O(z,w)) for NORM_HAMMING2; identity for NORM_HAMMING
+template <bool NORM2>
+__device__ __forceinline__ uint4 pack_cells(uint4 v) {
+    if (!NORM2) return v;
+    uint4 r;
+    r.x = (v.x & 0x55555555u) | ((v.y & 0x55555555u) << 1);
+    r.y = (v.z & 0x55555555u) | ((v.w & 0x55555555u) << 1);
+    r.z = ((v.x >> 1) & 0x55555555u) | (v.y & 0xAAAAAAAAu);
+    r.w = ((v.z >> 1) & 0x55555555u) | (v.w & 0xAAAAAAAAu);
+    return r;
+}
+
+// popcount(x) + acc in one instruction (the compiler otherwise splits pairs into bcnt, bcnt, add3)
+__device__ __forceinline__ unsigned bcnt_acc(unsigned x, unsigned acc) {
+    unsigned r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+template <bool NORM2>
+__device__ __forceinline__ unsigned dist_quad(const uint4 &a, const uint4 &b, unsigned acc) {
+    if (NORM2) {
+        // gfx950 v_bitop3_b32, truth table 0xde = (s0 ^ s2) | s1: differing cells of an (E, O) pair in 2 ops
+        acc = bcnt_acc(__builtin_amdgcn_bitop3_b32(a.x, a.z ^ b.z, b.x, 0xde), acc);
+        acc = bcnt_acc(__builtin_amdgcn_bitop3_b32(a.y, a.w ^ b.w, b.y, 0xde), acc);
+    } else {
+        acc = bcnt_acc(a.x ^ b.x, acc);
+        acc = bcnt_acc(a.y ^ b.y, acc);
+        acc = bcnt_acc(a.z ^ b.z, acc);
+        acc = bcnt_acc(a.w ^ b.w, acc);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void top2_insert(unsigned &m1, unsigned &m2, unsigned key) {
+    // m1 <= m2 invariant; median(m1, m2, key) is the new second best
+    unsigned med;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(med) : "v"(m1), "v"(m2), "v"(key));
+    m2 = med;
+    m1 = min(m1, key);
+}
+
+// FUSED: cross-check scatter straight from the all-pairs kernel (nsplit == 1).
+template <bool NORM2, bool FUSED>
+__global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
+    __shared__ uint4 tile[2][TILE_B * 4];
+
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
+    // range of logical blocks; the A tiles of one problem then share one L2 for their B rows.
+    const unsigned nblk = gridDim.x;
+    const unsigned logical = (blockIdx.x % 8u) * (nblk / 8u) + blockIdx.x / 8u;
+    const unsigned total = (unsigned)mb.tiles_per_prob * (unsigned)mb.n_prob;
+    if (logical >= total) return;
+    const int p = logical / mb.tiles_per_prob;
+    const int tile_a = logical % mb.tiles_per_prob;
+    const int split = blockIdx.y;
+
+    const uint4 *A, *B;
+    int na, nb;
+    if (mb.prob_a) {
+        const int ia = mb.prob_a[p], ib = mb.prob_b[p];
+        A = mb.desc + (size_t)ia * mb.n_max * 4;
+        B = mb.desc + (size_t)ib * mb.n_max * 4;
+        na = mb.count[ia];
+        nb = mb.count[ib];
+    } else {
+        A = mb.a_ptr;
+        B = mb.b_ptr;
+        na = mb.na;
+        nb = mb.nb;
+    }
+    const int row0 = tile_a * TILE_A;
+    if (row0 >= na) return;
+
+    // B range of this split, in whole tiles
+    const int tiles_b = (nb + TILE_B - 1) / TILE_B;
+    const int tiles_per_split = (tiles_b + mb.nsplit - 1) / mb.nsplit;
+    const int tb0 = split * tiles_per_split;
+    const int tb1 = min(tiles_b, tb0 + tiles_per_split);
+
+    const int tid = threadIdx.x;
+    uint4 a[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int row = row0 + r * BLOCK + tid;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < na) v = A[(size_t)row * 4 + c];
+            a[r][c] = pack_cells<NORM2>(v);
+        }
+    }
+    unsigned m1[ROWS], m2[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) m1[r] = m2[r] = NONE;
+
+    // prologue: first tile -> LDS.  A tile is TILE_B*4 = 512 uint4; each thread moves 4 of them, coalesced.
+    uint4 stage[4];
+    auto load_tile = [&](int tb) {
+        const size_t base = (size_t)tb * TILE_B * 4;
+        const size_t lim = (size_t)nb * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t idx = base + k * BLOCK + tid;
+            stage[k] = idx < lim ? B[idx] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tile[buf][k * BLOCK + tid] = pack_cells<NORM2>(stage[k]);
+    };
+
+    if (tb0 < tb1) {
+        load_tile(tb0);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int tb = tb0; tb < tb1; ++tb) {
+        const int buf = (tb - tb0) & 1;
+        const bool more = tb + 1 < tb1;
+        if (more) load_tile(tb + 1);                 // global loads in flight during the compute below
+
+        const int jbase = tb * TILE_B;
+        const int rows_here = min(TILE_B, nb - jbase);
+        const uint4 *t = tile[buf];
+        for (int j = 0; j < rows_here; ++j) {
+            const uint4 b0 = t[j * 4 + 0], b1 = t[j * 4 + 1], b2 = t[j * 4 + 2], b3 = t[j * 4 + 3];
+            const unsigned jg = (unsigned)(jbase + j);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                unsigned d = 0;
+                d = dist_quad<NORM2>(a[r][0], b0, d);
+                d = dist_quad<NORM2>(a[r][1], b1, d);
+                d = dist_quad<NORM2>(a[r][2], b2, d);
+                d = dist_quad<NORM2>(a[r][3], b3, d);
+                top2_insert(m1[r], m2[r], (d << SLAM_KEY_SHIFT) | jg);
+            }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int row = row0 + r * BLOCK + tid;
+        if (row >= na) continue;
+        if (FUSED) {
+            // A = train rows, B = query rows: scatter (distance, train row) into the nearest query's slot
+            if (m1[r] != NONE) {
+                const unsigned q = m1[r] & (SLAM_MAX_ROWS - 1);
+                const unsigned key = (m1[r] & ~(unsigned)(SLAM_MAX_ROWS - 1)) | (unsigned)row;
+                atomicMin(mb.out1 + (size_t)p * mb.out_stride + q, key);
+            }
+        } else {
+            const size_t o = (size_t)p * mb.out_stride + (size_t)split * na + row;
+            mb.out1[o] = m1[r];
+            if (mb.out2) mb.out2[o] = m2[r];
+        }
+    }
+}
+
+// merges per-split partial top-2 lists of one problem; mode cross-check scatters, mode knn2 writes keys
+__global__ void merge_splits_kernel(const unsigned *part1, const unsigned *part2, int na, int nsplit, int crosscheck,
+                                    unsigned *out1, unsigned *out2) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= na) return;
+    unsigned m1 = NONE, m2 = NONE;
+    for (int s = 0; s < nsplit; ++s) {
+        top2_insert(m1, m2, part1[(size_t)s * na + row]);
+        if (part2) top2_insert(m1, m2, part2[(size_t)s * na + row]);
+    }
+    if (crosscheck) {
+        if (m1 != NONE) {
+            const unsigned q = m1 & (SLAM_MAX_ROWS - 1);
+            atomicMin(out1 + q, (m1 & ~(unsigned)(SLAM_MAX_ROWS - 1)) | (unsigned)row);
+        }
+    } else {
+        out1[row] = m1;
+        if (out2) out2[row] = m2;
+    }
+}
+
+__global__ void unpack_keys_kernel(const unsigned *key, int n, int *index, int *distance) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned k = key[i];
+    index[i] = k == NONE ? -1 : (int)(k & (SLAM_MAX_ROWS - 1));
+    distance[i] = k == NONE ? INT32_MAX : (int)(k >> SLAM_KEY_SHIFT);
+}
+
+template <bool FUSED>
+void launch_allpairs(const MatchBatch &mb, int norm, hipStream_t st) {
+    const unsigned total = (unsigned)mb.tiles_per_prob * (unsigned)mb.n_prob;
+    dim3 grid((total + 7u) / 8u * 8u, mb.nsplit);
+    if (norm == SLAM_NORM_HAMMING2)
+        hipLaunchKernelGGL((allpairs_top2_kernel<true, FUSED>), grid, dim3(BLOCK), 0, st, mb);
+    else
+        hipLaunchKernelGGL((allpairs_top2_kernel<false, FUSED>), grid, dim3(BLOCK), 0, st, mb);
+}
+
+int pick_nsplit(int na, int nb) {
+    const int tiles_a = slam_div_up(na, TILE_A), tiles_b = slam_div_up(nb, TILE_B);
+    int ns = 1024 / (tiles_a > 0 ? tiles_a : 1);
+    if (ns > tiles_b) ns = tiles_b;
+    if (ns > 64) ns = 64;
+    return ns < 1 ? 1 : ns;
+}
+
+}  // namespace
+
+extern "C" size_t slam_match_workspace_bytes(int n_query, int n_train) {
+    const size_t n = (size_t)(n_query > n_train ? n_query : n_train);
+    return 2 * 64 * n * sizeof(unsigned) + 256;
+}
+
+extern "C" int slam_match_hamming(const uint8_t *d_query, int n_query, const uint8_t *d_train, int n_train, int norm,
+                                  int mode, uint32_t *d_key1, uint32_t *d_key2, void *d_workspace,
+                                  size_t workspace_bytes, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SLAM_REQUIRE(norm == SLAM_NORM_HAMMING || norm == SLAM_NORM_HAMMING2, "slam_match_hamming: norm %d unsupported", norm);
+    SLAM_REQUIRE(mode == SLAM_MATCH_CROSSCHECK || mode == SLAM_MATCH_KNN2, "slam_match_hamming: mode %d unsupported", mode);
+    SLAM_REQUIRE(n_query >= 0 && n_train >= 0 && n_query < SLAM_MAX_ROWS && n_train < SLAM_MAX_ROWS,
+                 "slam_match_hamming: row counts %d/%d out of range", n_query, n_train);
+    if (n_query == 0) return SLAM_OK;
+    SLAM_REQUIRE(d_key1 && (mode == SLAM_MATCH_CROSSCHECK || d_key2), "slam_match_hamming: null output");
+    SLAM_REQUIRE(d_query && (d_train || n_train == 0), "slam_match_hamming: null input");
+    SLAM_REQUIRE(((uintptr_t)d_query & 15) == 0 && ((uintptr_t)d_train & 15) == 0,
+                 "slam_match_hamming: descriptor rows must be 16-byte aligned");
+    const bool cross = mode == SLAM_MATCH_CROSSCHECK;
+    SLAM_HIP_CHECK(hipMemsetAsync(d_key1, 0xFF, sizeof(uint32_t) * (size_t)n_query, st));
+    if (!cross) SLAM_HIP_CHECK(hipMemsetAsync(d_key2, 0xFF, sizeof(uint32_t) * (size_t)n_query, st));
+    if (n_train == 0) return SLAM_OK;
+
+    MatchBatch mb{};
+    // cross-check: lanes own TRAIN rows and scan the queries; knn: lanes own QUERY rows and scan the trains
+    mb.a_ptr = (const uint4 *)(cross ? d_train : d_query);
+    mb.b_ptr = (const uint4 *)(cross ? d_query : d_train);
+    mb.na = cross ? n_train : n_query;
+    mb.nb = cross ? n_query : n_train;
+    mb.n_prob = 1;
+    mb.tiles_per_prob = slam_div_up(mb.na, TILE_A);
+    mb.nsplit = pick_nsplit(mb.na, mb.nb);
+    const size_t need = 2 * (size_t)mb.nsplit * mb.na * sizeof(unsigned);
+    if (workspace_bytes < need || !d_workspace) {
+        slam_set_error("slam_match_hamming: workspace %zu B < %zu B", workspace_bytes, need);
+        return SLAM_E_WORKSPACE;
+    }
+    unsigned *part1 = (unsigned *)d_workspace;
+    unsigned *part2 = part1 + (size_t)mb.nsplit * mb.na;
+    mb.out1 = part1;
+    mb.out2 = cross ? nullptr : part2;
+    mb.out_stride = 0;
+    launch_allpairs<false>(mb, norm, st);
+    SLAM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(merge_splits_kernel, dim3(slam_div_up(mb.na, 256)), dim3(256), 0, st, part1, mb.out2, mb.na,
+                       mb.nsplit, cross ? 1 : 0, d_key1, d_key2);
+    SLAM_HIP_CHECK(hipGetLastError());
+    return SLAM_OK;
+}
+
+extern "C" int slam_match_hamming_batched(const uint8_t *d_desc, const int32_t *d_count, int n_max,
+                                          const int32_t *d_prob_query, const int32_t *d_prob_train, int n_prob,
+                                          int norm, int mode, uint32_t *d_key1, uint32_t *d_key2, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SLAM_REQUIRE(norm == SLAM_NORM_HAMMING || norm == SLAM_NORM_HAMMING2, "slam_match_hamming_batched: norm %d", norm);
+    SLAM_REQUIRE(mode == SLAM_MATCH_CROSSCHECK || mode == SLAM_MATCH_KNN2, "slam_match_hamming_batched: mode %d", mode);
+    SLAM_REQUIRE(n_max > 0 && n_max < SLAM_MAX_ROWS && n_prob >= 0, "slam_match_hamming_batched: bad sizes");
+    if (n_prob == 0) return SLAM_OK;
+    SLAM_REQUIRE(d_desc && d_count && d_prob_query && d_prob_train && d_key1 && (mode == SLAM_MATCH_CROSSCHECK || d_key2),
+                 "slam_match_hamming_batched: null pointer");
+    SLAM_REQUIRE(((uintptr_t)d_desc & 15) == 0, "slam_match_hamming_batched: descriptors must be 16-byte aligned");
+    const bool cross = mode == SLAM_MATCH_CROSSCHECK;
+    SLAM_HIP_CHECK(hipMemsetAsync(d_key1, 0xFF, sizeof(uint32_t) * (size_t)n_prob * n_max, st));
+    if (!cross) SLAM_HIP_CHECK(hipMemsetAsync(d_key2, 0xFF, sizeof(uint32_t) * (size_t)n_prob * n_max, st));
+    MatchBatch mb{};
+    mb.desc = (const uint4 *)d_desc;
+    mb.count = d_count;
+    mb.prob_a = cross ? d_prob_train : d_prob_query;
+    mb.prob_b = cross ? d_prob_query : d_prob_train;
+    mb.n_max = n_max;
+    mb.n_prob = n_prob;
+    mb.tiles_per_prob = slam_div_up(n_max, TILE_A);
+    mb.nsplit = 1;
+    mb.out1 = d_key1;
+    mb.out2 = cross ? nullptr : d_key2;
+    mb.out_stride = n_max;
+    if (cross)
+        launch_allpairs<true>(mb, norm, st);
+    else
+        launch_allpairs<false>(mb, norm, st);   // nsplit == 1: partial slot 0 is the final answer
+    SLAM_HIP_CHECK(hipGetLastError());
+    return SLAM_OK;
+}
+
+extern "C" int slam_unpack_keys(const uint32_t *d_key, int n, int32_t *d_index, int32_t *d_distance, void *stream) {
+    if (n <= 0) return SLAM_OK;
+    SLAM_REQUIRE(d_key && d_index && d_distance, "slam_unpack_keys: null pointer");
+    hipLaunchKernelGGL(unpack_keys_kernel, dim3(slam_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, d_key, n,
+                       d_index, d_distance);
+    SLAM_HIP_CHECK(hipGetLastError());
+    return SLAM_OK;
+}

@@ -1,0 +1,135 @@
+// Host side of the RANSAC loop: the reference's random stream and its adaptive stopping rule.
+//
+// utils/utills.py:502 draws np.random.randint(0, n, 4) from numpy's legacy global generator: MT19937
+// seeded by init_genrand, 32-bit outputs, bounded by masked rejection (numpy/random/src/distributions:
+// buffered_bounded_masked_uint32).  north_star: "the reference's random minimal samples are reproduced on the
+// host".  The raw 32-bit words do not depend on n, so they are generated here while the GPU is still matching;
+// the rejection step (which needs n = number of tracked points) runs on the device (p3p.hip, map_samples).
+#include "ransac_host.h"
+
+#include <cmath>
+
+namespace {
+
+struct MT19937 {
+    uint32_t mt[624];
+    int pos;
+    explicit MT19937(uint32_t seed) {
+        for (int i = 0; i < 624; ++i) {
+            mt[i] = seed;
+            seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)i + 1u;
+        }
+        pos = 624;
+    }
+    void twist() {
+        const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, A = 0x9908b0dfu;
+        int k = 0;
+        for (; k < 624 - 397; ++k) {
+            const uint32_t y = (mt[k] & UP) | (mt[k + 1] & LO);
+            mt[k] = mt[k + 397] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        }
+        for (; k < 623; ++k) {
+            const uint32_t y = (mt[k] & UP) | (mt[k + 1] & LO);
+            mt[k] = mt[k + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        }
+        const uint32_t y = (mt[623] & UP) | (mt[0] & LO);
+        mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        pos = 0;
+    }
+    inline uint32_t next() {
+        if (pos >= 624) twist();
+        uint32_t y = mt[pos++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+};
+
+}  // namespace
+
+void slam_mt_seed_words(uint32_t seed, uint32_t *out, int n_words) {
+    MT19937 g(seed);
+    for (int i = 0; i < n_words; ++i) out[i] = g.next();
+}
+
+extern "C" int slam_mt19937_words(uint32_t seed, uint32_t *h_words, int n_words) {
+    if (n_words < 0 || (!h_words && n_words)) {
+        slam_set_error("slam_mt19937_words: bad arguments");
+        return SLAM_E_INVALID;
+    }
+    slam_mt_seed_words(seed, h_words, n_words);
+    return SLAM_OK;
+}
+
+extern "C" long slam_randint_host(uint32_t seed, uint32_t bound, int32_t *h_out, long n_out) {
+    if (bound == 0) {
+        slam_set_error("slam_randint_host: low >= high");   // numpy raises ValueError
+        return SLAM_E_EMPTY;
+    }
+    if (n_out < 0 || (!h_out && n_out)) {
+        slam_set_error("slam_randint_host: bad arguments");
+        return SLAM_E_INVALID;
+    }
+    const uint32_t rng = bound - 1u;
+    if (rng == 0) {
+        for (long i = 0; i < n_out; ++i) h_out[i] = 0;
+        return 0;
+    }
+    uint32_t mask = rng;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    MT19937 g(seed);
+    long used = 0;
+    for (long i = 0; i < n_out; ++i) {
+        uint32_t v;
+        do {
+            v = g.next() & mask;
+            ++used;
+        } while (v > rng);
+        h_out[i] = (int32_t)v;
+    }
+    return used;
+}
+
+// ---- the adaptive loop of online_est_pnp_ransac (utils/utills.py:488-523), replayed over batched results ----
+bool RansacReplay::wants_more(const RansacParams &p) const {
+    if (p.fixed_iterations > 0) return it < p.fixed_iterations;
+    if (outliers_perc == 0.0) return false;
+    // first_loop_iter_est(prob, outliers_perc) = log(1 - prob) / log(1 - (1 - outliers_perc) ** model_parm_num)
+    const double est = std::log(1.0 - p.prob) / std::log(1.0 - std::pow(1.0 - outliers_perc, 4.0));
+    return (double)it < est && (double)it < p.max_iterations;
+}
+
+void RansacReplay::consume(const RansacParams &p, int n_points, const uint8_t *status, const int32_t *count,
+                           int draw_begin, int draw_end) {
+    // status/count are indexed by (draw - draw_begin)
+    while (!finished) {
+        if (!wants_more(p)) {
+            finished = true;
+            break;
+        }
+        if (draws >= p.max_draws) {
+            finished = true;
+            hit_cap = true;
+            break;
+        }
+        if (draws >= draw_end) break;            // need another round
+        const int d = draws++;
+        if (!status[d - draw_begin]) continue;   // utills.py:506-507: failed PnP is not an iteration
+        const int num = count[d - draw_begin];
+        if (num > max_supp) {                    // strict: the first best wins (utills.py:514)
+            max_supp = num;
+            best_draw = d;
+        }
+        ++it;
+        outl += n_points - num;
+        inl += num;
+        const double perc = (double)outl / (double)(inl + outl);
+        outliers_perc = perc < 0.99 ? perc : 0.99;
+    }
+}

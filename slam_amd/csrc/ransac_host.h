@@ -1,0 +1,25 @@
+// Host replay of the reference's adaptive RANSAC loop (utils/utills.py:474-530).
+#pragma once
+#include "common.h"
+
+struct RansacParams {
+    double prob = 0.9999;
+    double max_iterations = 1e3;
+    int fixed_iterations = 0;
+    int max_draws = 64000;
+};
+
+struct RansacReplay {
+    int it = 0;               // counted iterations (first_loop_iter)
+    int draws = 0;            // draws consumed from the stream, failed ones included
+    long long inl = 0, outl = 0;
+    double outliers_perc = 0.99;
+    int max_supp = -1;
+    int best_draw = -1;
+    bool finished = false;
+    bool hit_cap = false;
+
+    bool wants_more(const RansacParams &p) const;
+    void consume(const RansacParams &p, int n_points, const uint8_t *status, const int32_t *count, int draw_begin,
+                 int draw_end);
+};

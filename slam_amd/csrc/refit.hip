@@ -1,0 +1,261 @@
+// PnP refit on the supporters: Levenberg-Marquardt on the left-image reprojection error, one wavefront per
+// frame pair.
+//
+// Replaces extra_refine -> pnp(world[mask], left1[mask], K, cv2.SOLVEPNP_ITERATIVE) (utils/utills.py:548-571,
+// :585-596).  cv2's ITERATIVE solver is a DLT initialisation followed by Levenberg-Marquardt (CvLevMarq, at
+// most 20 iterations, relative step < FLT_EPSILON) on the pixel reprojection error of the LEFT camera only;
+// it therefore returns the local least-squares minimum to ~1e-7 relative.  This kernel minimises the same
+// cost to convergence, started from the winning RANSAC hypothesis (which already explains every supporter to
+// within 4 px, so it lies in the same basin), with a left-multiplied se(3) increment instead of OpenCV's
+// (rvec, tvec) parameters.  Same minimiser, hence the 1e-5 relative pose tolerance of the parity tests;
+// OpenCV itself is absent, so this is "parity unpinned" against cv2 and pinned against oracle/slam_oracle.py.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;   // xor butterfly: every lane ends with the same bits
+}
+
+// Cholesky solve of the 6x6 SPD system A x = b (upper triangle of A given, row-major full storage)
+__device__ __forceinline__ bool chol_solve6(double (&A)[6][6], const double (&b)[6], double (&x)[6]) {
+    double L[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < j) d -= L[j][k] * L[j][k];
+        if (!(d > 0.0)) return false;
+        const double s = sqrt(d);
+        L[j][j] = s;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (i > j) {
+                double v = A[j][i];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (k < j) v -= L[i][k] * L[j][k];
+                L[i][j] = v / s;
+            }
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = b[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < i) v -= L[i][k] * y[k];
+        y[i] = v / L[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double v = y[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k > i) v -= L[k][i] * x[k];
+        x[i] = v / L[i][i];
+    }
+    return true;
+}
+
+struct Pose { double R[3][3]; double t[3]; };
+
+// P' = exp(d) * P with d = (omega, upsilon): R' = E R, t' = E t + upsilon
+__device__ __forceinline__ Pose apply_step(const Pose &P, const double (&d)[6]) {
+    const double wx = d[0], wy = d[1], wz = d[2];
+    const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+    double a, b;   // E = I + a [w]x + b [w]x^2
+    if (th < 1e-8) {
+        a = 1.0 - th2 / 6.0;
+        b = 0.5 - th2 / 24.0;
+    } else {
+        a = sin(th) / th;
+        b = (1.0 - cos(th)) / th2;
+    }
+    const double W[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+    double E[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double w2 = W[i][0] * W[0][j] + W[i][1] * W[1][j] + W[i][2] * W[2][j];
+            E[i][j] = (i == j ? 1.0 : 0.0) + a * W[i][j] + b * w2;
+        }
+    Pose Q;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Q.R[i][j] = E[i][0] * P.R[0][j] + E[i][1] * P.R[1][j] + E[i][2] * P.R[2][j];
+        Q.t[i] = E[i][0] * P.t[0] + E[i][1] * P.t[1] + E[i][2] * P.t[2] + d[3 + i];
+    }
+    return Q;
+}
+
+constexpr int MAX_EVAL = 60;
+
+__global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, const float4 *xy1, const int *count,
+                                                   int seg_stride, const unsigned long long *mask_words,
+                                                   const double *pose0, double *pose_out, uint8_t *status) {
+    const int seg = blockIdx.x, lane = threadIdx.x;
+    const int n = count[seg];
+    const int words = seg_stride / 64;
+    const unsigned long long *mw = mask_words + (size_t)seg * words;
+    const double *Xs = X + (size_t)seg * seg_stride * 3;
+    const float4 *obs = xy1 + (size_t)seg * seg_stride;
+    const double fx = K.m[0], fy = K.m[4], cx = K.m[2], cy = K.m[5];
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+
+    int supp = 0;
+    for (int w = lane; w * 64 < n; w += 64) supp += __popcll(mw[w]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) supp += __shfl_xor(supp, m);
+    if (supp < 6) {   // utills.py:558-559: pose None
+        if (lane < 12) pose_out[(size_t)seg * 12 + lane] = qnan;
+        if (lane == 0) status[seg] = 0;
+        return;
+    }
+
+    Pose P;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) P.R[i][j] = pose0[(size_t)seg * 12 + i * 4 + j];
+        P.t[i] = pose0[(size_t)seg * 12 + i * 4 + 3];
+    }
+
+    auto cost_of = [&](const Pose &Q) {
+        double c = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            if (i < n && ((mw[i >> 6] >> (i & 63)) & 1ull)) {
+                const double x = Xs[i * 3], y = Xs[i * 3 + 1], z = Xs[i * 3 + 2];
+                const double xc = Q.R[0][0] * x + Q.R[0][1] * y + Q.R[0][2] * z + Q.t[0];
+                const double yc = Q.R[1][0] * x + Q.R[1][1] * y + Q.R[1][2] * z + Q.t[1];
+                const double zc = Q.R[2][0] * x + Q.R[2][1] * y + Q.R[2][2] * z + Q.t[2];
+                const float4 o = obs[i];
+                const double ru = fx * xc / zc + cx - (double)o.x, rv = fy * yc / zc + cy - (double)o.y;
+                c += ru * ru + rv * rv;
+            }
+        }
+        return wave_sum(c);
+    };
+
+    double lambda = 1e-3;
+    double cost = cost_of(P);
+    int evals = 0;
+    bool done = false;
+    while (!done && evals < MAX_EVAL) {
+        // normal equations at P
+        double H[21], g[6];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) H[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g[k] = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            if (i < n && ((mw[i >> 6] >> (i & 63)) & 1ull)) {
+                const double x = Xs[i * 3], y = Xs[i * 3 + 1], z = Xs[i * 3 + 2];
+                const double xc = P.R[0][0] * x + P.R[0][1] * y + P.R[0][2] * z + P.t[0];
+                const double yc = P.R[1][0] * x + P.R[1][1] * y + P.R[1][2] * z + P.t[1];
+                const double zc = P.R[2][0] * x + P.R[2][1] * y + P.R[2][2] * z + P.t[2];
+                const double iz = 1.0 / zc;
+                const float4 o = obs[i];
+                const double ru = fx * xc * iz + cx - (double)o.x, rv = fy * yc * iz + cy - (double)o.y;
+                // d(u,v)/dXc
+                const double ux = fx * iz, uz = -fx * xc * iz * iz, vy = fy * iz, vz = -fy * yc * iz * iz;
+                // dXc/d(omega) = -[Xc]x, dXc/d(upsilon) = I
+                const double Ju[6] = {uz * yc, ux * zc - uz * xc, -ux * yc, ux, 0.0, uz};
+                const double Jv[6] = {-vy * zc + vz * yc, -vz * xc, vy * xc, 0.0, vy, vz};
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                    for (int b = a; b < 6; ++b) H[k++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+                    g[a] += Ju[a] * ru + Jv[a] * rv;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 21; ++k) H[k] = wave_sum(H[k]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g[k] = wave_sum(g[k]);
+
+        bool stepped = false;
+        while (!stepped && evals < MAX_EVAL) {
+            double A[6][6], rhs[6], d[6];
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                for (int b = a; b < 6; ++b) {
+                    A[a][b] = H[k];
+                    A[b][a] = H[k];
+                    ++k;
+                }
+                rhs[a] = -g[a];
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) A[a][a] *= 1.0 + lambda;   // Marquardt scaling, as CvLevMarq
+            ++evals;
+            if (!chol_solve6(A, rhs, d)) {
+                lambda *= 10.0;
+                if (lambda > 1e16) done = true, stepped = true;
+                continue;
+            }
+            const Pose Q = apply_step(P, d);
+            const double c2 = cost_of(Q);
+            double dn = 0, pn = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) dn += d[a] * d[a];
+            pn = 1.0 + P.t[0] * P.t[0] + P.t[1] * P.t[1] + P.t[2] * P.t[2];
+            if (c2 <= cost) {
+                P = Q;
+                const bool tiny = dn <= 1e-26 * pn || (cost - c2) <= 1e-15 * cost;
+                cost = c2;
+                lambda = fmax(lambda * 0.1, 1e-16);
+                stepped = true;
+                if (tiny) done = true;
+            } else {
+                lambda *= 10.0;
+                if (lambda > 1e16 || dn <= 1e-30 * pn) done = true, stepped = true;
+            }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pose_out[(size_t)seg * 12 + i * 4 + j] = P.R[i][j];
+            pose_out[(size_t)seg * 12 + i * 4 + 3] = P.t[i];
+        }
+        status[seg] = 1;
+    }
+}
+
+}  // namespace
+
+int slam_launch_refit(const Mat33 &K, const double *d_X, const float *d_xy1, const int32_t *d_count, int n_seg,
+                      int seg_stride, const uint64_t *d_mask_words, const double *d_pose0, double *d_pose,
+                      uint8_t *d_status, hipStream_t st) {
+    if (n_seg <= 0) return SLAM_OK;
+    SLAM_REQUIRE(seg_stride % 64 == 0, "slam_refit_pnp: seg_stride must be a multiple of 64");
+    hipLaunchKernelGGL(refit_kernel, dim3(n_seg), dim3(64), 0, st, K, d_X, (const float4 *)d_xy1, d_count, seg_stride,
+                       (const unsigned long long *)d_mask_words, d_pose0, d_pose, d_status);
+    SLAM_HIP_CHECK(hipGetLastError());
+    return SLAM_OK;
+}
+
+extern "C" int slam_refit_pnp(const double *h_K, const double *d_X, const float *d_xy1, const int32_t *d_count,
+                              int n_seg, int seg_stride, const uint64_t *d_mask_words, const double *d_pose0,
+                              double *d_pose, uint8_t *d_status, void *stream) {
+    SLAM_REQUIRE(h_K && d_X && d_xy1 && d_count && d_mask_words && d_pose0 && d_pose && d_status,
+                 "slam_refit_pnp: null pointer");
+    Mat33 K;
+    for (int i = 0; i < 9; ++i) K.m[i] = h_K[i];
+    return slam_launch_refit(K, d_X, d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status,
+                             (hipStream_t)stream);
+}

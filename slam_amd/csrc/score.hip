@@ -1,0 +1,158 @@
+// Consensus scoring: one wavefront per pose hypothesis, 64 points per step, ballot + popcount.
+//
+// Replaces consensus_match (utils/utills.py:533-545) -> compose_transformations (:659-669),
+// find_supporters_4_frame (:672-695), project (:698-705), check_projection (:708-716) and
+// compute_square_dist (:719-736).
+//
+// The arithmetic follows numpy's operation order so that the supporter masks are the reference's, bit for bit,
+// for the same pose matrix:
+//   - `calib @ T`, `M2 @ [T; 0 0 0 1]` and `X @ P[:, :3].T` go through BLAS dgemm, whose kernels accumulate
+//     k = 0, 1, 2(, 3) with fused multiply-adds from a zero accumulator (checked against numpy/OpenBLAS in the
+//     build container): c = fma(a2, b2, fma(a1, b1, a0 * b0)).
+//   - `+ P[:, 3]`, the two divisions by the third homogeneous coordinate, `proj - obs`, the products and the sum
+//     inside np.linalg.norm, the square root and the comparison are separate correctly rounded operations.
+//   - the test is sqrt(dx*dx + dy*dy) <= acc**2 (the reference compares the UN-squared distance with acc squared);
+//     no positive-depth test; NaN compares false.
+// Compiled with -ffp-contract=off, so nothing below is fused except the explicit fma() calls.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+struct Proj { double p[12]; };
+
+// dst(3x4) = A(3x3) * B(3x4), BLAS accumulation order
+__device__ __forceinline__ void gemm_33_34(const double *A, const double *B, double *dst) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            dst[i * 4 + j] = fma(A[i * 3 + 2], B[8 + j], fma(A[i * 3 + 1], B[4 + j], A[i * 3 + 0] * B[j]));
+}
+
+// dst(3x4) = M(3x4) * [T; 0 0 0 1](4x4)
+__device__ __forceinline__ void compose_34(const double *M, const double *T, double *dst) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double last = j == 3 ? 1.0 : 0.0;
+            dst[i * 4 + j] = fma(M[i * 4 + 3], last, fma(M[i * 4 + 2], T[8 + j], fma(M[i * 4 + 1], T[4 + j], M[i * 4 + 0] * T[j])));
+        }
+}
+
+__device__ __forceinline__ bool within(const double *P, double x, double y, double z, double u, double v, double thr) {
+    const double hx = fma(z, P[2], fma(y, P[1], x * P[0])) + P[3];
+    const double hy = fma(z, P[6], fma(y, P[5], x * P[4])) + P[7];
+    const double hz = fma(z, P[10], fma(y, P[9], x * P[8])) + P[11];
+    const double dx = hx / hz - u, dy = hy / hz - v;
+    return sqrt(dx * dx + dy * dy) <= thr;
+}
+
+constexpr int SB = 256;   // 4 waves = 4 hypotheses of the same segment per workgroup (shared L1 footprint)
+
+__global__ __launch_bounds__(SB) void score_kernel(Mat33 K, Mat34 M2, const double *X, const float4 *xy1,
+                                                   const int *count, const int *seg_of, int seg_stride,
+                                                   const double *pose, const uint8_t *status, int n_hyp, double thr,
+                                                   int *inlier_count, unsigned long long *mask) {
+    const int row = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = blockIdx.x * (SB / 64) + wave;
+    if (h >= n_hyp) return;
+    const int seg = seg_of ? seg_of[row] : row;
+    const int n = count[seg];
+    const size_t o = (size_t)row * n_hyp + h;
+    const int words = seg_stride / 64;
+    unsigned long long *mrow = mask ? mask + o * words : nullptr;
+    const bool live = status[o] != 0;
+
+    double T[12], Tr[12], Pl[12], Pr[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = pose[o * 12 + i];
+    compose_34(M2.m, T, Tr);
+    gemm_33_34(K.m, T, Pl);
+    gemm_33_34(K.m, Tr, Pr);
+
+    const double *Xs = X + (size_t)seg * seg_stride * 3;
+    const float4 *obs = xy1 + (size_t)seg * seg_stride;
+    int total = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        bool ok = false;
+        if (live && i < n) {
+            const double x = Xs[i * 3 + 0], y = Xs[i * 3 + 1], z = Xs[i * 3 + 2];
+            const float4 c = obs[i];
+            ok = within(Pl, x, y, z, (double)c.x, (double)c.y, thr) && within(Pr, x, y, z, (double)c.z, (double)c.w, thr);
+        }
+        const unsigned long long bal = __ballot(ok);
+        total += __popcll(bal);
+        if (mrow && lane == 0) mrow[base >> 6] = bal;
+    }
+    if (lane == 0) inlier_count[o] = total;
+    if (mrow) {
+        for (int w = (n + 63) / 64 + lane; w < words; w += 64) mrow[w] = 0ull;
+    }
+}
+
+// drop-in consensus_match: float64 observations, one pose, byte mask
+__global__ __launch_bounds__(256) void consensus_f64_kernel(Mat33 K, Mat34 M2, Mat34 T, const double *X,
+                                                            const double2 *l1, const double2 *r1, int n, double thr,
+                                                            uint8_t *mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double Tr[12], Pl[12], Pr[12];
+    compose_34(M2.m, T.m, Tr);
+    gemm_33_34(K.m, T.m, Pl);
+    gemm_33_34(K.m, Tr, Pr);
+    const double x = X[(size_t)i * 3], y = X[(size_t)i * 3 + 1], z = X[(size_t)i * 3 + 2];
+    const double2 a = l1[i], b = r1[i];
+    mask[i] = within(Pl, x, y, z, a.x, a.y, thr) && within(Pr, x, y, z, b.x, b.y, thr);
+}
+
+}  // namespace
+
+int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const float *d_xy1, const int32_t *d_count,
+                      const int32_t *d_seg_of, int n_rows, int seg_stride, const double *d_pose,
+                      const uint8_t *d_status, int n_hyp, double thr, int32_t *d_inlier_count, uint64_t *d_mask,
+                      hipStream_t st) {
+    if (n_rows <= 0 || n_hyp <= 0) return SLAM_OK;
+    SLAM_REQUIRE(n_rows <= 65535, "slam_score_hypotheses: more than 65535 segments per call");
+    SLAM_REQUIRE(!d_mask || seg_stride % 64 == 0, "slam_score_hypotheses: seg_stride must be a multiple of 64 for masks");
+    hipLaunchKernelGGL(score_kernel, dim3(slam_div_up(n_hyp, SB / 64), n_rows), dim3(SB), 0, st, K, M2, d_X,
+                       (const float4 *)d_xy1, d_count, d_seg_of, seg_stride, d_pose, d_status, n_hyp, thr,
+                       d_inlier_count, (unsigned long long *)d_mask);
+    SLAM_HIP_CHECK(hipGetLastError());
+    return SLAM_OK;
+}
+
+extern "C" int slam_score_hypotheses(const double *h_K, const double *h_M2, const double *d_X, const float *d_xy1,
+                                     const int32_t *d_count, int n_seg, int seg_stride, const double *d_pose,
+                                     const uint8_t *d_status, int n_hyp, double thr, int32_t *d_inlier_count,
+                                     uint64_t *d_mask, void *stream) {
+    SLAM_REQUIRE(h_K && h_M2 && d_X && d_xy1 && d_count && d_pose && d_status && d_inlier_count,
+                 "slam_score_hypotheses: null pointer");
+    Mat33 K;
+    Mat34 M2;
+    for (int i = 0; i < 9; ++i) K.m[i] = h_K[i];
+    for (int i = 0; i < 12; ++i) M2.m[i] = h_M2[i];
+    return slam_launch_score(K, M2, d_X, d_xy1, d_count, nullptr, n_seg, seg_stride, d_pose, d_status, n_hyp, thr,
+                             d_inlier_count, d_mask, (hipStream_t)stream);
+}
+
+extern "C" int slam_consensus_match_f64(const double *h_K, const double *h_M2, const double *h_pose,
+                                        const double *d_X, const double *d_left1, const double *d_right1, int n,
+                                        double thr, uint8_t *d_mask, void *stream) {
+    if (n <= 0) return SLAM_OK;
+    SLAM_REQUIRE(h_K && h_M2 && h_pose && d_X && d_left1 && d_right1 && d_mask, "slam_consensus_match_f64: null pointer");
+    Mat33 K;
+    Mat34 M2, T;
+    for (int i = 0; i < 9; ++i) K.m[i] = h_K[i];
+    for (int i = 0; i < 12; ++i) {
+        M2.m[i] = h_M2[i];
+        T.m[i] = h_pose[i];
+    }
+    hipLaunchKernelGGL(consensus_f64_kernel, dim3(slam_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, K, M2, T,
+                       d_X, (const double2 *)d_left1, (const double2 *)d_right1, n, thr, d_mask);
+    SLAM_HIP_CHECK(hipGetLastError());
+    return SLAM_OK;
+}

@@ -1,0 +1,125 @@
+"""Batched shard pipeline: all frame pairs of a frame range through libslam_amd's slam_track_pairs.
+
+This is the host-side counterpart of the loop in find_features_in_consecutive_frames_whole_movie
+(utils/utills.py:834-873): detections in (device tensors), relative poses + supporter sets out (numpy)."""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .config import HotPathConfig
+
+
+@dataclass
+class ShardResult:
+    pose: np.ndarray          # float64[n_pairs, 3, 4]; NaN where the reference returns None
+    stats: np.ndarray         # int32[n_pairs, 8]: T, supporters, iterations, draws, best draw, status, n stereo0, n temporal
+    mask: np.ndarray          # bool[n_pairs, n_max]  supporters among the tracked correspondences (pre-refit)
+    tracked_kp: torch.Tensor  # int32[n_pairs, n_max, 4] on the device: key-point indices (L0, R0, L1, R1)
+    timing_ms: np.ndarray     # float64[8], see slam_track_last_timing
+
+    @property
+    def tracked(self):
+        return self.stats[:, 0]
+
+    @property
+    def supporters(self):
+        return self.stats[:, 1]
+
+    @property
+    def ok(self):
+        return (self.stats[:, 5] & _lib.SLAM_PAIR_OK) != 0
+
+    def inliers_percentage(self):
+        """utills.py:923."""
+        t = np.maximum(self.tracked, 1)
+        return 100.0 * self.supporters / t
+
+
+def _track_config(cfg: HotPathConfig) -> _lib.SlamTrackConfig:
+    c = _lib.SlamTrackConfig()
+    c.K[:] = np.asarray(cfg.K, np.float64).reshape(9).tolist()
+    c.M1[:] = np.asarray(cfg.M1, np.float64).reshape(12).tolist()
+    c.M2[:] = np.asarray(cfg.M2, np.float64).reshape(12).tolist()
+    c.rec_err, c.acc, c.prob, c.max_iterations = cfg.rec_err, cfg.supp_err, cfg.prob, cfg.max_iterations
+    c.fixed_iterations, c.max_draws, c.norm, c.first_chunk = cfg.fixed_iterations, cfg.max_draws, cfg.norm, cfg.first_chunk
+    return c
+
+
+class ShardTracker:
+    """Owns the device/pinned workspaces for shards of up to (n_frames, n_pairs, n_max) and runs them."""
+
+    def __init__(self, n_frames: int, n_pairs: int, n_max: int, cfg: HotPathConfig | None = None):
+        self.cfg = cfg or HotPathConfig()
+        self.n_frames, self.n_pairs, self.n_max = n_frames, n_pairs, n_max
+        if n_max % 64:
+            raise ValueError("n_max must be a multiple of 64")
+        self.dev = ops.device()
+        self._c = _track_config(self.cfg)
+        L = _lib.lib()
+        self.d_ws_bytes = L.slam_track_device_workspace_bytes(n_frames, n_pairs, n_max, ctypes.byref(self._c))
+        self.h_ws_bytes = L.slam_track_host_workspace_bytes(n_frames, n_pairs, n_max, ctypes.byref(self._c))
+        self.d_ws = torch.empty(self.d_ws_bytes, dtype=torch.uint8, device=self.dev)
+        self.h_ws = torch.empty(self.h_ws_bytes, dtype=torch.uint8).pin_memory()
+        self.tracked_kp = torch.zeros((n_pairs, n_max, 4), dtype=torch.int32, device=self.dev)
+        self.h_pose = torch.empty((n_pairs, 12), dtype=torch.float64).pin_memory()
+        self.h_stats = torch.empty((n_pairs, 8), dtype=torch.int32).pin_memory()
+        self.h_mask = torch.empty((n_pairs, n_max // 64), dtype=torch.int64).pin_memory()
+
+    def run(self, desc: torch.Tensor, xy: torch.Tensor, count: torch.Tensor, pair_f0: np.ndarray, pair_f1: np.ndarray,
+            seeds: np.ndarray, unpack_mask: bool = True) -> ShardResult:
+        """desc uint8[2F, n_max, 64], xy float32[2F, n_max, 2], count int32[2F] on the device (image 2f = left of
+        frame f, 2f+1 = right); pair_f0/f1 int32[P] frame indices; seeds uint32[P] (np.random.seed per pair)."""
+        F = desc.shape[0] // 2
+        P = len(pair_f0)
+        if F > self.n_frames or P > self.n_pairs or desc.shape[1] != self.n_max:
+            raise ValueError("shard larger than the tracker's workspace")
+        f0 = np.ascontiguousarray(pair_f0, dtype=np.int32)
+        f1 = np.ascontiguousarray(pair_f1, dtype=np.int32)
+        sd = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64) & 0xFFFFFFFF, dtype=np.uint32)
+        io = _lib.SlamTrackIO()
+        io.d_desc, io.d_xy, io.d_count = ops._dev(desc, torch.uint8), ops._dev(xy, torch.float32), ops._dev(count, torch.int32)
+        io.n_frames, io.n_max = F, self.n_max
+        io.h_pair_f0, io.h_pair_f1, io.h_pair_seed = f0.ctypes.data, f1.ctypes.data, sd.ctypes.data
+        io.n_pairs = P
+        io.d_tracked_kp = self.tracked_kp.data_ptr()
+        io.h_pose, io.h_stats, io.h_mask = self.h_pose.data_ptr(), self.h_stats.data_ptr(), self.h_mask.data_ptr()
+        io.d_workspace, io.d_workspace_bytes = self.d_ws.data_ptr(), self.d_ws_bytes
+        io.h_workspace, io.h_workspace_bytes = self.h_ws.data_ptr(), self.h_ws_bytes
+        L = _lib.lib()
+        _lib.check(L.slam_track_pairs(ctypes.byref(self._c), ctypes.byref(io), ops._stream()))
+        tm = np.zeros(8)
+        L.slam_track_last_timing(tm.ctypes.data)
+        pose = self.h_pose[:P].numpy().reshape(P, 3, 4).copy()
+        stats = self.h_stats[:P].numpy().copy()
+        if unpack_mask:
+            mask = ops.mask_words_to_bool(self.h_mask[:P].numpy(), self.n_max)
+        else:
+            mask = self.h_mask[:P].numpy().copy()
+        return ShardResult(pose=pose, stats=stats, mask=mask, tracked_kp=self.tracked_kp[:P], timing_ms=tm)
+
+
+def consecutive_pairs(n_frames: int):
+    f0 = np.arange(n_frames - 1, dtype=np.int32)
+    return f0, f0 + 1
+
+
+def compose_global(rel: np.ndarray, first=None) -> np.ndarray:
+    """convert_trans_from_rel_to_global (utils/utills.py:749-757): running left-composition
+    T_i @ [T_{i-1..}; 0 0 0 1].  rel float64[n, 3, 4] (rel[0] = the first camera, [I|0])."""
+    out = np.empty_like(rel)
+    last = rel[0] if first is None else first
+    for i in range(len(rel)):
+        hom = np.vstack([last, [0.0, 0.0, 0.0, 1.0]])
+        last = rel[i] @ hom
+        out[i] = last
+    return out
+
+
+def camera_centres(glob: np.ndarray) -> np.ndarray:
+    """left_cameras_trajectory / relative_camera_pos (utils/utills.py:599-606, :785-794): -R^T t."""
+    return np.array([-1 * t[:, :3].T @ t[:, 3] for t in glob]).reshape(-1, 3)

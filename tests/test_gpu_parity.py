@@ -1,0 +1,289 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference's golden vectors.
+
+Bars: bit-exact for match lists, joins, sample indices and inlier masks/counts; 1e-5 relative (north_star) for
+triangulated points and poses (written next to each assert; most are far tighter in practice)."""
+import numpy as np
+import pytest
+import torch
+
+import c_oracle
+import slam_oracle as orc
+from slam_amd import _lib, ops
+from slam_amd.synth import SynthConfig, SynthSequence
+
+pytestmark = pytest.mark.gpu
+
+K, M1, M2 = orc.K, orc.M1, orc.M2
+REL_TOL = 1e-5
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def gpu_crosscheck(q, t, norm):
+    k1, _ = ops.match_keys(dev(ops.pad_descriptors(q)), dev(ops.pad_descriptors(t)), norm, _lib.SLAM_MATCH_CROSSCHECK)
+    idx, dist = ops.unpack_keys(k1)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    qi = np.nonzero(idx >= 0)[0].astype(np.int32)
+    return qi, idx[qi], dist[qi]
+
+
+@pytest.mark.parametrize("norm", [orc.NORM_HAMMING2, orc.NORM_HAMMING])
+@pytest.mark.parametrize("shape", [(1, 1), (1, 300), (300, 1), (64, 64), (129, 513), (1000, 777), (2000, 1987), (3000, 5000)])
+def test_crosscheck_match_bit_exact(norm, shape):
+    rng = np.random.default_rng(shape[0] * 7919 + shape[1] + norm)
+    nq, nt = shape
+    # few distinct byte values -> many equal distances -> tie-breaks matter
+    q = rng.integers(0, 4, (nq, 61), dtype=np.uint8)
+    t = rng.integers(0, 4, (nt, 61), dtype=np.uint8)
+    t[: min(nq, nt) // 2] = q[: min(nq, nt) // 2]          # exact duplicates (distance 0 ties)
+    want = c_oracle.match_crosscheck(q, t, norm)
+    got = gpu_crosscheck(q, t, norm)
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+
+
+def test_crosscheck_match_random_full_bytes():
+    rng = np.random.default_rng(11)
+    q = rng.integers(0, 256, (2000, 61), dtype=np.uint8)
+    t = rng.integers(0, 256, (2011, 61), dtype=np.uint8)
+    want = c_oracle.match_crosscheck(q, t, orc.NORM_HAMMING2)
+    got = gpu_crosscheck(q, t, orc.NORM_HAMMING2)
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+
+
+def test_match_empty_inputs():
+    q = np.zeros((0, 61), np.uint8)
+    t = np.random.default_rng(0).integers(0, 256, (10, 61), dtype=np.uint8)
+    assert len(gpu_crosscheck(q, t, orc.NORM_HAMMING2)[0]) == 0
+    assert len(gpu_crosscheck(t, q, orc.NORM_HAMMING2)[0]) == 0
+
+
+@pytest.mark.parametrize("norm", [orc.NORM_HAMMING2, orc.NORM_HAMMING])
+@pytest.mark.parametrize("shape", [(5, 2), (200, 333), (1500, 2100)])
+def test_knn2_bit_exact(norm, shape):
+    rng = np.random.default_rng(shape[0] + 31 * shape[1])
+    q = rng.integers(0, 8, (shape[0], 61), dtype=np.uint8)
+    t = rng.integers(0, 8, (shape[1], 61), dtype=np.uint8)
+    idx_w, dist_w = c_oracle.knn2(q, t, norm)
+    k1, k2 = ops.match_keys(dev(ops.pad_descriptors(q)), dev(ops.pad_descriptors(t)), norm, _lib.SLAM_MATCH_KNN2)
+    i1, d1 = (x.cpu().numpy() for x in ops.unpack_keys(k1))
+    i2, d2 = (x.cpu().numpy() for x in ops.unpack_keys(k2))
+    assert np.array_equal(np.stack([i1, i2], 1), idx_w)
+    assert np.array_equal(np.stack([d1, d2], 1), dist_w)
+
+
+def _small_sequence(n_frames=5, n_features=300, seed=3):
+    cfg = SynthConfig(n_frames=40, n_features=n_features, seed=seed, spawn_per_frame=40, ragged=13)
+    seq = SynthSequence(cfg)
+    desc, xy, count = seq.frames(0, n_frames)
+    return seq, desc, xy, count
+
+
+def test_batched_match_and_join_bit_exact():
+    seq, desc, xy, count = _small_sequence()
+    F, _, n_max, _ = desc.shape
+    d_desc = dev(desc.reshape(2 * F, n_max, 64))
+    d_xy = dev(xy.reshape(2 * F, n_max, 2))
+    d_count = dev(count.reshape(2 * F))
+    fr = torch.arange(F, dtype=torch.int32).cuda()
+    skey, _ = ops.match_keys_batched(d_desc, d_count, (2 * fr).int(), (2 * fr + 1).int())
+    f0 = torch.arange(F - 1, dtype=torch.int32).cuda()
+    f1 = f0 + 1
+    tkey, _ = ops.match_keys_batched(d_desc, d_count, (2 * f0).int(), (2 * f1).int())
+    tcount, kp, xy0, xy1 = ops.rect_filter_join(d_xy, d_count, skey, tkey, f0, f1, 2.0)
+    sidx, sdist = (x.cpu().numpy() for x in ops.unpack_keys(skey))
+    tcount, kp, xy0, xy1 = tcount.cpu().numpy(), kp.cpu().numpy(), xy0.cpu().numpy(), xy1.cpu().numpy()
+
+    def frame(i):
+        n0, n1 = count[i]
+        return dict(dsc_l=desc[i, 0, :n0, :61], dsc_r=desc[i, 1, :n1, :61], xy_l=xy[i, 0, :n0], xy_r=xy[i, 1, :n1])
+
+    stereo = []
+    for i in range(F):
+        f = frame(i)
+        q, t, d = c_oracle.match_crosscheck(f["dsc_l"], f["dsc_r"])
+        qi = np.nonzero(sidx[i] >= 0)[0]
+        assert np.array_equal(qi, q) and np.array_equal(sidx[i][qi], t) and np.array_equal(sdist[i][qi], d)
+        rec, _ = orc.rect_filter(f["xy_l"][:, 1], f["xy_r"][:, 1], q, t)
+        stereo.append((q, t, d, rec))
+    for p in range(F - 1):
+        a, b = frame(p), frame(p + 1)
+        tq, tt, _ = c_oracle.match_crosscheck(a["dsc_l"], b["dsc_l"])
+        ia, ib, _ = orc.join_4view(stereo[p][0], stereo[p][3], stereo[p + 1][0], stereo[p + 1][3], tq, tt)
+        want = np.stack([stereo[p][0][ia], stereo[p][1][ia], stereo[p + 1][0][ib], stereo[p + 1][1][ib]], 1)
+        T = tcount[p]
+        assert T == len(want) and T > 50
+        assert np.array_equal(kp[p, :T], want)
+        assert np.array_equal(xy0[p, :T, :2], a["xy_l"][want[:, 0]]) and np.array_equal(xy0[p, :T, 2:], a["xy_r"][want[:, 1]])
+        assert np.array_equal(xy1[p, :T, :2], b["xy_l"][want[:, 2]]) and np.array_equal(xy1[p, :T, 2:], b["xy_r"][want[:, 3]])
+
+
+def _rel_err(a, b):
+    return np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-300)
+
+
+def test_triangulate_against_reference_golden(golden):
+    xl, xr, want = golden["tri_xl"], golden["tri_xr"], golden["tri_X"]
+    got = ops.triangulate_f64(K @ M1, K @ M2, dev(xl), dev(xr)).cpu().numpy()
+    err = _rel_err(got, want)
+    assert np.all(err <= REL_TOL), err.max()            # north_star: 1e-5 relative
+    # float32-coordinate batched entry point, ragged segments
+    xy = np.zeros((2, 448, 4), np.float32)
+    xy[0, :400] = np.hstack([xl, xr]).astype(np.float32)
+    xy[1, :100] = xy[0, 100:200]
+    cnt = np.array([400, 100], np.int32)
+    X = ops.triangulate(K @ M1, K @ M2, dev(xy), dev(cnt)).cpu().numpy()
+    assert np.all(_rel_err(X[0, :400], want) <= REL_TOL) and np.all(_rel_err(X[1, :100], want[100:200]) <= REL_TOL)
+    assert not X[1, 100:].any() and not X[0, 400:].any()
+
+
+def test_consensus_masks_bit_exact_against_reference_golden(golden):
+    g = golden
+    X, l1, r1 = g["cons_X"], g["cons_l1"], g["cons_r1"]
+    m = ops.consensus_match_f64(K, M2, g["cons_T"], dev(X), dev(l1), dev(r1), 4.0).cpu().numpy().astype(bool)
+    assert np.array_equal(m, g["cons_mask"])
+    Tnan = np.hstack([np.eye(3), np.full((3, 1), np.nan)])
+    assert not ops.consensus_match_f64(K, M2, Tnan, dev(X), dev(l1), dev(r1), 4.0).cpu().numpy().any()
+    # batched scoring entry point: counts and bit masks for 48 hypotheses (+1 failed, +1 NaN)
+    n, stride = len(X), 640
+    Xs = np.zeros((1, stride, 3))
+    Xs[0, :n] = X
+    xy1 = np.zeros((1, stride, 4), np.float32)
+    xy1[0, :n] = np.hstack([l1, r1]).astype(np.float32)                 # golden observations are float32-exact
+    pose = np.concatenate([g["score_T"], g["score_T"][:1], Tnan[None]])[None]
+    status = np.ones((1, pose.shape[1]), np.uint8)
+    status[0, -2] = 0
+    cnt, mask = ops.score_hypotheses(K, M2, dev(Xs), dev(xy1), dev(np.array([n], np.int32)), dev(pose), dev(status), 4.0,
+                                     want_mask=True)
+    cnt, mask = cnt.cpu().numpy()[0], ops.mask_words_to_bool(mask.cpu().numpy()[0], n)
+    H = len(g["score_T"])
+    assert np.array_equal(mask[:H], g["score_masks"])
+    assert np.array_equal(cnt[:H], g["score_masks"].sum(1))
+    assert cnt[H] == 0 and cnt[H + 1] == 0 and not mask[H:].any()
+
+
+def test_scoring_bit_exact_large_random():
+    rng = np.random.default_rng(77)
+    n, H, stride = 1900, 96, 1920
+    X = np.stack([rng.uniform(-30, 30, n), rng.uniform(-5, 4, n), rng.uniform(-5, 100, n)], 1)
+    T0 = np.hstack([orc.rodrigues_vec_to_mat(np.array([0.004, -0.02, 0.003])), np.array([[0.03], [-0.01], [-0.9]])])
+    l1 = (orc.project(X, K @ T0) + rng.normal(0, 2.5, (n, 2))).astype(np.float32)
+    r1 = (orc.project(X, K @ orc.compose(T0, M2)) + rng.normal(0, 2.5, (n, 2))).astype(np.float32)
+    Ts = np.array([np.hstack([orc.rodrigues_vec_to_mat(np.array([0.004, -0.02, 0.003]) + rng.normal(0, 0.002, 3)),
+                              (T0[:, 3] + rng.normal(0, 0.02, 3))[:, None]]) for _ in range(H)])
+    with np.errstate(all="ignore"):
+        want = np.array([orc.consensus_match(K, Ts[h], M2, X, l1.astype(np.float64), r1.astype(np.float64), 2) for h in range(H)])
+    Xs = np.zeros((1, stride, 3))
+    Xs[0, :n] = X
+    xy1 = np.zeros((1, stride, 4), np.float32)
+    xy1[0, :n] = np.hstack([l1, r1])
+    cnt, mask = ops.score_hypotheses(K, M2, dev(Xs), dev(xy1), dev(np.array([n], np.int32)), dev(Ts[None]),
+                                     dev(np.ones((1, H), np.uint8)), 4.0, want_mask=True)
+    got = ops.mask_words_to_bool(mask.cpu().numpy()[0], n)
+    assert np.array_equal(got, want)
+    assert np.array_equal(cnt.cpu().numpy()[0], want.sum(1))
+    assert 0.05 < want.mean() < 0.95
+
+
+def _ransac_problem(rng, n=500, frac_out=0.2):
+    T0 = np.hstack([orc.rodrigues_vec_to_mat(np.array([0.01, -0.03, 0.005])), np.array([[0.05], [-0.02], [-0.8]])])
+    X = np.stack([rng.uniform(-20, 20, n), rng.uniform(-4, 3, n), rng.uniform(4, 70, n)], 1)
+    l = orc.project(X, K @ T0) + rng.normal(0, 0.3, (n, 2))
+    r = orc.project(X, K @ orc.compose(T0, M2)) + rng.normal(0, 0.3, (n, 2))
+    bad = rng.random(n) < frac_out
+    l[bad] += rng.normal(0, 30, (int(bad.sum()), 2))
+    return T0, X, l.astype(np.float32), r.astype(np.float32)
+
+
+def test_p3p_hypotheses_against_oracle():
+    rng = np.random.default_rng(5)
+    T0, X, l, r = _ransac_problem(rng)
+    n, stride, H = len(X), 512, 400
+    sample = rng.integers(0, n, (1, H, 4)).astype(np.int32)
+    sample[0, 0] = [3, 3, 9, 11]            # repeated point: degenerate, NaN pose but status 1
+    sample[0, 1] = [5, 6, 6, 6]
+    Xs = np.zeros((1, stride, 3))
+    Xs[0, :n] = X
+    xy1 = np.zeros((1, stride, 4), np.float32)
+    xy1[0, :n] = np.hstack([l, r])
+    pose, status = ops.p3p_hypotheses(K, dev(Xs), dev(xy1), dev(np.array([n], np.int32)), dev(sample))
+    pose, status = pose.cpu().numpy()[0], status.cpu().numpy()[0]
+    n_ok = n_fail = n_nan = 0
+    with np.errstate(all="ignore"):
+        for h in range(H):
+            idx = sample[0, h]
+            want = orc.pnp(X[idx], l[idx].astype(np.float64), K, orc.SOLVEPNP_AP3P)
+            if want is None:
+                assert status[h] == 0
+                n_fail += 1
+                continue
+            assert status[h] == 1
+            if not np.all(np.isfinite(want)):
+                assert not np.all(np.isfinite(pose[h]))
+                n_nan += 1
+                continue
+            # 1e-5 relative on the pose (north_star); ill-conditioned minimal samples amplify rounding, so the
+            # norm is taken over the whole 3x4 matrix
+            err = np.linalg.norm(pose[h] - want) / np.linalg.norm(want)
+            assert err <= REL_TOL, (h, err)
+            n_ok += 1
+    assert n_ok > 200 and n_nan >= 2
+
+
+def test_refit_against_oracle():
+    rng = np.random.default_rng(8)
+    T0, X, l, r = _ransac_problem(rng, n=700, frac_out=0.25)
+    n, stride = len(X), 704
+    with np.errstate(all="ignore"):
+        Th = orc.pnp(X[[1, 2, 3, 4]], orc.project(X[[1, 2, 3, 4]], K @ T0), K, orc.SOLVEPNP_AP3P)
+        mask = orc.consensus_match(K, Th, M2, X, l.astype(np.float64), r.astype(np.float64), 2)
+        want = orc.pnp(X[mask], l[mask].astype(np.float64), K, orc.SOLVEPNP_ITERATIVE)
+    Xs = np.zeros((2, stride, 3))
+    Xs[:, :n] = X
+    xy1 = np.zeros((2, stride, 4), np.float32)
+    xy1[:, :n] = np.hstack([l, r])
+    few = np.zeros(n, bool)
+    few[:5] = True                                                   # < 6 supporters -> pose None
+    words = ops.bool_to_mask_words(np.stack([mask, few]), stride)
+    pose, status = ops.refit_pnp(K, dev(Xs), dev(xy1), dev(np.array([n, n], np.int32)), dev(words), dev(np.stack([Th, Th])))
+    pose, status = pose.cpu().numpy(), status.cpu().numpy()
+    assert list(status) == [1, 0] and np.isnan(pose[1]).all()
+    err = np.linalg.norm(pose[0] - want) / np.linalg.norm(want)
+    assert err <= REL_TOL, err                                        # north_star: 1e-5 relative
+
+
+def test_full_pipeline_against_oracle_sequence():
+    from slam_amd.pipeline import ShardTracker, consecutive_pairs
+    seq, desc, xy, count = _small_sequence(n_frames=6, n_features=320, seed=9)
+    F, _, n_max, _ = desc.shape
+    trk = ShardTracker(F, F - 1, n_max)
+    f0, f1 = consecutive_pairs(F)
+    seeds = 1000 + np.arange(F - 1)
+    res = trk.run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)), f0, f1, seeds)
+    kp = res.tracked_kp.cpu().numpy()
+
+    def frame(i):
+        n0, n1 = count[i]
+        return dict(dsc_l=desc[i, 0, :n0, :61], dsc_r=desc[i, 1, :n1, :61], xy_l=xy[i, 0, :n0], xy_r=xy[i, 1, :n1])
+
+    for p in range(F - 1):
+        np.random.seed(int(seeds[p]))
+        st = {}
+        with np.errstate(all="ignore"):
+            want = orc.track_pair(frame(p), frame(p + 1), stats=st)
+        T = len(want["kp"])
+        assert res.stats[p, 0] == T
+        assert np.array_equal(kp[p, :T], want["kp"])
+        assert res.stats[p, 2] == st["iterations"] and res.stats[p, 3] == st["draws"] and res.stats[p, 4] == st["best_draw"]
+        assert np.array_equal(res.mask[p, :T], want["mask"]) and not res.mask[p, T:].any()
+        assert res.stats[p, 1] == want["mask"].sum()
+        err = np.linalg.norm(res.pose[p] - want["T"]) / np.linalg.norm(want["T"])
+        assert err <= REL_TOL, (p, err)
+        gt = seq.gt_relative(p + 1)
+        assert np.abs(res.pose[p] - gt).max() < 0.05
