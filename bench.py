@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""Benchmark of the stereo-trajectory hot path (BASELINE.json metric: frame-pairs/s for
+match + triangulate + PnP-RANSAC on synthetic KITTI-shaped stereo, 3450 frames x ~2k features per image).
+
+    python bench.py --gpus N --steps K --warmup W         (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the whole hot path over one shard: 3450 stereo frames (3449 frame pairs) whose
+detections are already resident in HBM, through to relative poses + supporter masks on the host.  With N ranks
+every rank owns its own 3450-frame range of a longer drive (weak scaling, no data-path collective); the only
+exchange is the RCCL all-gather of the relative poses and per-pair counters before rank 0 composes the global
+trajectory, as north_star describes.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Peak used for the matcher's roofline: MI355X vector ALU issue rate for full-rate 32-bit integer ops,
+# 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md: FP32 vector peak 157.3 TFLOP/s = 2 flop x this rate).
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+HBM_PEAK_GBPS = 8000.0
+# VALU instructions the matcher executes per descriptor pair (NORM_HAMMING2, 64-byte rows): 8 x (v_xor, v_bitop3,
+# v_bcnt) + v_lshl_or + v_min + v_med3; SURVEY section 8(d) counts the naive formulation at 80 (+4) per pair.
+EXEC_OPS_PER_PAIR = 27
+SURVEY_OPS_PER_PAIR = 80
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=3450)
+    ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--cpu-pairs", type=int, default=24, help="frame pairs timed through the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from slam_amd import pipeline
+    from slam_amd.config import HotPathConfig
+    from slam_amd.synth import SynthConfig, SynthSequence
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    # ---- synthetic detections of this rank's frame range (outside the timed region) ----
+    F = args.frames
+    scfg = SynthConfig(n_frames=F, n_features=args.features, seed=args.seed + 7919 * rank)
+    seq = SynthSequence(scfg)
+    t0 = time.time()
+    desc, xy, count = seq.frames(0, F)
+    gen_s = time.time() - t0
+    n_max = scfg.n_max
+    d_desc = torch.from_numpy(desc.reshape(2 * F, n_max, 64)).cuda()
+    d_xy = torch.from_numpy(xy.reshape(2 * F, n_max, 2)).cuda()
+    d_count = torch.from_numpy(count.reshape(2 * F)).cuda()
+    f0, f1 = pipeline.consecutive_pairs(F)
+    P = len(f0)
+    seeds = 1000 + rank * P + np.arange(P)            # np.random.seed(1000 + pair index)
+    cfg = HotPathConfig()
+    trk = pipeline.ShardTracker(F, P, n_max, cfg)
+
+    gathered_pose = torch.empty((world, P, 12), dtype=torch.float64, device="cuda") if world > 1 else None
+    gathered_stat = torch.empty((world, P, 8), dtype=torch.int32, device="cuda") if world > 1 else None
+
+    def step():
+        res = trk.run(d_desc, d_xy, d_count, f0, f1, seeds, unpack_mask=False)
+        if world > 1:
+            # the one exchange of the path: relative poses + counters to every rank (RCCL over xGMI)
+            dist.all_gather_into_tensor(gathered_pose, trk.h_pose[:P].cuda(non_blocking=True))
+            dist.all_gather_into_tensor(gathered_stat, trk.h_stats[:P].cuda(non_blocking=True))
+            rel_all = gathered_pose.cpu().numpy().reshape(world * P, 3, 4)
+        else:
+            rel_all = res.pose
+        glob = None
+        if rank == 0:
+            # host-side composition (utils/utills.py:749-757); pairs with no pose keep the previous camera
+            rel = np.where(np.isfinite(rel_all).all(axis=(1, 2), keepdims=True), rel_all, np.eye(3, 4)[None])
+            glob = pipeline.compose_global(np.concatenate([np.eye(3, 4)[None], rel[:P]]))
+        return res, glob
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    match_ms, stage_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, glob = step()
+        match_ms.append(res.timing_ms[0])
+        stage_ms.append(res.timing_ms.copy())
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * P * args.steps / elapsed
+        # ---- roofline of the dominant kernel (all-pairs matcher), from HIP events on the launch stream ----
+        cnt = count.astype(np.int64)
+        pairs_stereo = int((cnt[:, 0] * cnt[:, 1]).sum())
+        pairs_temporal = int((cnt[:-1, 0] * cnt[1:, 0]).sum())
+        desc_pairs = pairs_stereo + pairs_temporal                    # descriptor pairs per step (two launches)
+        m_ms = float(np.mean(match_ms))
+        exec_rate = desc_pairs * EXEC_OPS_PER_PAIR / (m_ms * 1e-3) / 1e12
+        alg_bytes = int(cnt.sum()) * 64 * 1 + (2 * F - 1) * n_max * 4  # every descriptor row once + the key arrays
+        stages = np.mean(np.array(stage_ms), axis=0)
+        roofline = {
+            "kernel": "allpairs_top2_kernel (2 launches per step: stereo + temporal)",
+            "bound": "valu", "unit": "Tlaneop/s",
+            "achieved": round(exec_rate, 3), "peak": round(VALU_PEAK_TLANEOPS, 2),
+            "frac": round(exec_rate / VALU_PEAK_TLANEOPS, 4),
+            "ops_per_descriptor_pair_executed": EXEC_OPS_PER_PAIR,
+            "achieved_survey_units": round(desc_pairs * SURVEY_OPS_PER_PAIR / (m_ms * 1e-3) / 1e12, 3),
+            "descriptor_pairs_per_step": desc_pairs, "kernel_ms_per_step": round(m_ms, 4),
+            "hbm_algorithmic_GBps": round(alg_bytes / (m_ms * 1e-3) / 1e9, 2), "hbm_peak_GBps": HBM_PEAK_GBPS,
+            "traffic": None,
+        }
+        # trajectory sanity: ATE of the composed trajectory against the generator's ground truth
+        centres = pipeline.camera_centres(glob)
+        gt = np.array([-seq.R_cw[i].T @ seq.t_cw[i] for i in range(F)])
+        ate = float(np.sqrt(np.mean(np.sum((centres - gt) ** 2, axis=1))))
+        out = {
+            "metric": "frame-pairs/sec (match+triangulate+PnP-RANSAC)", "value": round(value, 2), "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 popcount + f64",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic KITTI-shaped stereo, {F} frames x {args.features} features/image per GPU "
+                                   f"(BASELINE configs[1]); {P} frame pairs per GPU per step",
+                       "descriptor_bytes": 61, "norm": "NORM_HAMMING2", "match": "cross-check brute force",
+                       "ransac": "adaptive (prob 0.9999, cap 1000), seeds 1000+pair", "parallelism": f"frame-range x{world}"},
+            "roofline": roofline,
+            "stage_ms": {"match": round(float(stages[0]), 3), "join": round(float(stages[1]), 3),
+                         "triangulate": round(float(stages[2]), 3), "ransac_rounds": round(float(stages[3]), 3),
+                         "mask_refit": round(float(stages[4]), 3), "call_wall": round(float(stages[5]), 3),
+                         "host_rng_replay": round(float(stages[6]), 3)},
+            "quality": {"ate_rmse_m_vs_ground_truth": round(ate, 4), "pairs_ok": int(res.ok.sum()), "pairs": P,
+                        "mean_tracked": round(float(res.tracked.mean()), 1),
+                        "mean_supporters": round(float(res.supporters.mean()), 1),
+                        "mean_iterations": round(float(res.stats[:, 2].mean()), 2)},
+            "setup_s": {"synthetic_generation": round(gen_s, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, seq, desc, xy, count, seeds, res, trk)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, seq, desc, xy, count, seeds, res, trk):
+    """The CPU oracle ("port": numpy restatement + C matcher, one thread) on a bounded sample of the same pairs,
+    timed on this box's host cores; also cross-checks the GPU results of those pairs."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    import slam_oracle as orc
+    orc.bf_match = lambda a, b, norm=7: c_oracle.match_crosscheck_w64(c_oracle.pad64(a), c_oracle.pad64(b), norm)
+    F = len(count)
+    n = min(args.cpu_pairs, F - 1)
+    picks = np.linspace(0, F - 2, n).astype(int)
+    kp = res.tracked_kp.cpu().numpy()
+    mask = __import__("slam_amd.ops", fromlist=["ops"]).mask_words_to_bool(res.mask, trk.n_max)
+
+    def frame(i):
+        n0, n1 = count[i]
+        return dict(dsc_l=desc[i, 0, :n0, :61], dsc_r=desc[i, 1, :n1, :61], xy_l=xy[i, 0, :n0], xy_r=xy[i, 1, :n1])
+
+    t_total, exact_kp, exact_mask, worst_pose = 0.0, 0, 0, 0.0
+    for p in picks:
+        a, b = frame(p), frame(p + 1)
+        a["stereo"] = orc.stereo_match(a["dsc_l"], a["dsc_r"], a["xy_l"], a["xy_r"])   # carried over from the previous pair
+        np.random.seed(int(seeds[p]))
+        t0 = time.perf_counter()
+        with np.errstate(all="ignore"):
+            want = orc.track_pair(a, b)
+        t_total += time.perf_counter() - t0
+        T = len(want["kp"])
+        exact_kp += int(res.stats[p, 0] == T and np.array_equal(kp[p, :T], want["kp"]))
+        exact_mask += int(np.array_equal(mask[p, :T], want["mask"]))
+        if want["T"] is not None:
+            worst_pose = max(worst_pose, float(np.linalg.norm(res.pose[p] - want["T"]) / np.linalg.norm(want["T"])))
+    return {"value": round(n / t_total, 3), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{n} of {F - 1} frame pairs of the same sequence (evenly spaced), CPU oracle: C 64-bit-popcount "
+                      f"cross-check matcher (one new stereo match + one temporal match per pair, as the reference's "
+                      f"steady state) + numpy triangulation / AP3P / consensus / LM refit",
+            "parity_on_sample": {"tracked_sets_bit_exact": f"{exact_kp}/{n}", "supporter_masks_bit_exact": f"{exact_mask}/{n}",
+                                 "worst_pose_rel_err": float(f"{worst_pose:.3e}")}}
+
+
+if __name__ == "__main__":
+    main()
