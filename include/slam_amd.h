@@ -125,15 +125,16 @@ long slam_randint_host(uint32_t seed, uint32_t bound, int32_t *h_out, long n_out
  * PnP hypotheses.  Replaces pnp(..., cv2.SOLVEPNP_AP3P) + rodriguez_to_mat (utils/utills.py:574-596,
  * call site :503): Ke & Roumeliotis AP3P on the first three sample points, the fourth picks the root.
  * Segment s (a frame pair) has d_count[s] points: d_X + s*seg_stride*3 (float64) and
- * d_xy1 + s*seg_stride*4 (float32 xL1,yL1,xR1,yR1; only the left pair is used).  d_sample holds
+ * d_xy1 + s*seg_stride*4 (xL1,yL1,xR1,yR1; float32 rows, or float64 rows when xy_f64 != 0 -- the drop-in
+ * wrappers receive float64 arrays; only the left pair is used).  d_sample holds
  * n_hyp x 4 point indices per segment ([n_seg][n_hyp][4] int32).  Outputs [n_seg][n_hyp]:
  *   d_pose[..][12]  row-major 3x4 [R|t] (NaN-filled where the sample is degenerate)
  *   d_status[..]    1 = pose returned, 0 = solver found no root (the reference's `continue`, :506-507)
  * h_K: row-major 3x3 calibration.
  */
-int slam_p3p_hypotheses(const double *h_K, const double *d_X, const float *d_xy1, const int32_t *d_count, int n_seg,
-                        int seg_stride, const int32_t *d_sample, int n_hyp, double *d_pose, uint8_t *d_status,
-                        void *stream);
+int slam_p3p_hypotheses(const double *h_K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count,
+                        int n_seg, int seg_stride, const int32_t *d_sample, int n_hyp, double *d_pose,
+                        uint8_t *d_status, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Consensus scoring.  Replaces consensus_match -> compose_transformations, find_supporters_4_frame,
@@ -145,7 +146,7 @@ int slam_p3p_hypotheses(const double *h_K, const double *d_X, const float *d_xy1
  * uint64 bit masks, bit i%64 of word i/64 = point i supports.  seg_stride must be a multiple of 64.
  * h_K 3x3, h_M2 3x4 row-major float64.
  */
-int slam_score_hypotheses(const double *h_K, const double *h_M2, const double *d_X, const float *d_xy1,
+int slam_score_hypotheses(const double *h_K, const double *h_M2, const double *d_X, const void *d_xy1, int xy_f64,
                           const int32_t *d_count, int n_seg, int seg_stride, const double *d_pose,
                           const uint8_t *d_status, int n_hyp, double thr, int32_t *d_inlier_count, uint64_t *d_mask,
                           void *stream);
@@ -160,7 +161,7 @@ int slam_consensus_match_f64(const double *h_K, const double *h_M2, const double
  * winning hypothesis.  Per segment: d_mask_words [seg_stride/64] uint64, d_pose0 [12] -> d_pose [12];
  * d_status: 1 = refit done, 0 = fewer than 6 supporters (pose None, :558-559), NaN-filled pose.
  */
-int slam_refit_pnp(const double *h_K, const double *d_X, const float *d_xy1, const int32_t *d_count, int n_seg,
+int slam_refit_pnp(const double *h_K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count, int n_seg,
                    int seg_stride, const uint64_t *d_mask_words, const double *d_pose0, double *d_pose,
                    uint8_t *d_status, void *stream);
 

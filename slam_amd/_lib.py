@@ -59,14 +59,14 @@ SIGNATURES = {
     "slam_triangulate_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "slam_mt19937_words": (c_int, [c_uint32, c_void_p, c_int]),
     "slam_randint_host": (c_long, [c_uint32, c_uint32, c_void_p, c_long]),
-    "slam_p3p_hypotheses": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
-                                    c_void_p, c_void_p]),
-    "slam_score_hypotheses": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+    "slam_p3p_hypotheses": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                    c_void_p, c_void_p, c_void_p]),
+    "slam_score_hypotheses": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
                                       c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "slam_consensus_match_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double,
                                          c_void_p, c_void_p]),
-    "slam_refit_pnp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p]),
+    "slam_refit_pnp": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p]),
     "slam_track_device_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_void_p]),
     "slam_track_host_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_void_p]),
     "slam_track_pairs": (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -15,14 +15,14 @@ int slam_launch_map_samples(const uint32_t *d_words, int words_per_seg, const in
                             hipStream_t st);
 
 // Hypotheses + scoring with an optional row -> segment indirection (rows = active pairs of a RANSAC round).
-int slam_launch_p3p(const Mat33 &K, const double *d_X, const float *d_xy1, const int32_t *d_count,
+int slam_launch_p3p(const Mat33 &K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count,
                     const int32_t *d_seg_of, int n_rows, int seg_stride, const int32_t *d_sample, int sample_stride,
                     int draw0, int n_hyp, double *d_pose, uint8_t *d_status, hipStream_t st);
-int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const float *d_xy1, const int32_t *d_count,
+int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count,
                       const int32_t *d_seg_of, int n_rows, int seg_stride, const double *d_pose,
                       const uint8_t *d_status, int n_hyp, double thr, int32_t *d_inlier_count, uint64_t *d_mask,
                       hipStream_t st);
-int slam_launch_refit(const Mat33 &K, const double *d_X, const float *d_xy1, const int32_t *d_count, int n_seg,
+int slam_launch_refit(const Mat33 &K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count, int n_seg,
                       int seg_stride, const uint64_t *d_mask_words, const double *d_pose0, double *d_pose,
                       uint8_t *d_status, hipStream_t st);
 int slam_launch_triangulate(const Mat34 &P, const Mat34 &Q, const float *d_xy, const int32_t *d_count, int n_seg,

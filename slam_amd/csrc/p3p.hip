@@ -334,7 +334,8 @@ __device__ int ap3p_pose(const Mat33 &K, const double (&X)[4][3], const double (
     return n_sol;
 }
 
-__global__ __launch_bounds__(64) void p3p_kernel(Mat33 K, const double *X, const float4 *xy1, const int *count,
+template <typename XY4>
+__global__ __launch_bounds__(64) void p3p_kernel(Mat33 K, const double *X, const XY4 *xy1, const int *count,
                                                  const int *seg_of, int seg_stride, const int *sample,
                                                  int sample_stride, int draw0, int n_hyp, double *pose,
                                                  uint8_t *status) {
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(64) void p3p_kernel(Mat33 K, const double *X, const
         Xs[k][0] = X[g * 3 + 0];
         Xs[k][1] = X[g * 3 + 1];
         Xs[k][2] = X[g * 3 + 2];
-        const float4 c = xy1[g];
+        const XY4 c = xy1[g];
         uv[k][0] = (double)c.x;
         uv[k][1] = (double)c.y;
     }
@@ -383,24 +384,29 @@ int slam_launch_map_samples(const uint32_t *d_words, int words_per_seg, const in
     return SLAM_OK;
 }
 
-int slam_launch_p3p(const Mat33 &K, const double *d_X, const float *d_xy1, const int32_t *d_count,
+int slam_launch_p3p(const Mat33 &K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count,
                     const int32_t *d_seg_of, int n_rows, int seg_stride, const int32_t *d_sample, int sample_stride,
                     int draw0, int n_hyp, double *d_pose, uint8_t *d_status, hipStream_t st) {
     if (n_rows <= 0 || n_hyp <= 0) return SLAM_OK;
     SLAM_REQUIRE(n_rows <= 65535, "slam_p3p_hypotheses: more than 65535 segments per call");
-    hipLaunchKernelGGL(p3p_kernel, dim3(slam_div_up(n_hyp, 64), n_rows), dim3(64), 0, st, K, d_X,
-                       (const float4 *)d_xy1, d_count, d_seg_of, seg_stride, d_sample, sample_stride, draw0, n_hyp,
-                       d_pose, d_status);
+    if (xy_f64)
+        hipLaunchKernelGGL(p3p_kernel<double4>, dim3(slam_div_up(n_hyp, 64), n_rows), dim3(64), 0, st, K, d_X,
+                           (const double4 *)d_xy1, d_count, d_seg_of, seg_stride, d_sample, sample_stride, draw0,
+                           n_hyp, d_pose, d_status);
+    else
+        hipLaunchKernelGGL(p3p_kernel<float4>, dim3(slam_div_up(n_hyp, 64), n_rows), dim3(64), 0, st, K, d_X,
+                           (const float4 *)d_xy1, d_count, d_seg_of, seg_stride, d_sample, sample_stride, draw0,
+                           n_hyp, d_pose, d_status);
     SLAM_HIP_CHECK(hipGetLastError());
     return SLAM_OK;
 }
 
-extern "C" int slam_p3p_hypotheses(const double *h_K, const double *d_X, const float *d_xy1, const int32_t *d_count,
-                                   int n_seg, int seg_stride, const int32_t *d_sample, int n_hyp, double *d_pose,
-                                   uint8_t *d_status, void *stream) {
+extern "C" int slam_p3p_hypotheses(const double *h_K, const double *d_X, const void *d_xy1, int xy_f64,
+                                   const int32_t *d_count, int n_seg, int seg_stride, const int32_t *d_sample,
+                                   int n_hyp, double *d_pose, uint8_t *d_status, void *stream) {
     SLAM_REQUIRE(h_K && d_X && d_xy1 && d_count && d_sample && d_pose && d_status, "slam_p3p_hypotheses: null pointer");
     Mat33 K;
     for (int i = 0; i < 9; ++i) K.m[i] = h_K[i];
-    return slam_launch_p3p(K, d_X, d_xy1, d_count, nullptr, n_seg, seg_stride, d_sample, n_hyp, 0, n_hyp, d_pose,
+    return slam_launch_p3p(K, d_X, d_xy1, xy_f64, d_count, nullptr, n_seg, seg_stride, d_sample, n_hyp, 0, n_hyp, d_pose,
                            d_status, (hipStream_t)stream);
 }

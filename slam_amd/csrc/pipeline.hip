@@ -275,9 +275,9 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
     // ---- 4. RANSAC round 0: D0 speculative draws for every pair ----
     rc = slam_launch_map_samples(b.words0, W0, b.tcount, nullptr, P, D0, b.sample0, b.produced0, st);
     if (rc) return rc;
-    rc = slam_launch_p3p(K, b.X, b.xy1, b.tcount, nullptr, P, N, b.sample0, D0, 0, D0, b.pose0, b.status0, st);
+    rc = slam_launch_p3p(K, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.sample0, D0, 0, D0, b.pose0, b.status0, st);
     if (rc) return rc;
-    rc = slam_launch_score(K, M2, b.X, b.xy1, b.tcount, nullptr, P, N, b.pose0, b.status0, D0, thr, b.cnt0, nullptr, st);
+    rc = slam_launch_score(K, M2, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.pose0, b.status0, D0, thr, b.cnt0, nullptr, st);
     if (rc) return rc;
     SLAM_HIP_CHECK(hipMemcpyAsync(b.h_tcount, b.tcount, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
     SLAM_HIP_CHECK(hipMemcpyAsync(b.h_aux, b.aux, sizeof(int32_t) * 2 * P, hipMemcpyDeviceToHost, st));
@@ -335,9 +335,9 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
             host_ms += now_ms() - t_h0;
             SLAM_HIP_CHECK(hipMemcpyAsync(b.seg_of, b.h_seg_of, sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
             SLAM_HIP_CHECK(hipMemcpyAsync(b.sampleR, b.h_sampleR, sizeof(int32_t) * (size_t)rows * n_eval * 4, hipMemcpyHostToDevice, st));
-            rc = slam_launch_p3p(K, b.X, b.xy1, b.tcount, b.seg_of, rows, N, b.sampleR, n_eval, 0, n_eval, b.poseR, b.statusR, st);
+            rc = slam_launch_p3p(K, b.X, b.xy1, 0, b.tcount, b.seg_of, rows, N, b.sampleR, n_eval, 0, n_eval, b.poseR, b.statusR, st);
             if (rc) return rc;
-            rc = slam_launch_score(K, M2, b.X, b.xy1, b.tcount, b.seg_of, rows, N, b.poseR, b.statusR, n_eval, thr, b.cntR, nullptr, st);
+            rc = slam_launch_score(K, M2, b.X, b.xy1, 0, b.tcount, b.seg_of, rows, N, b.poseR, b.statusR, n_eval, thr, b.cntR, nullptr, st);
             if (rc) return rc;
             SLAM_HIP_CHECK(hipMemcpyAsync(b.h_statusR, b.statusR, (size_t)rows * n_eval, hipMemcpyDeviceToHost, st));
             SLAM_HIP_CHECK(hipMemcpyAsync(b.h_cntR, b.cntR, sizeof(int32_t) * (size_t)rows * n_eval, hipMemcpyDeviceToHost, st));
@@ -366,9 +366,9 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
     SLAM_HIP_CHECK(hipEventRecord(g_ev[4], st));
 
     // ---- 5. supporter mask of the winner (pre-refit, as the reference returns) + refit ----
-    rc = slam_launch_score(K, M2, b.X, b.xy1, b.tcount, nullptr, P, N, b.best_pose, b.best_status, 1, thr, b.best_cnt, b.mask, st);
+    rc = slam_launch_score(K, M2, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.best_pose, b.best_status, 1, thr, b.best_cnt, b.mask, st);
     if (rc) return rc;
-    rc = slam_launch_refit(K, b.X, b.xy1, b.tcount, P, N, b.mask, b.best_pose, b.refit_pose, b.refit_status, st);
+    rc = slam_launch_refit(K, b.X, b.xy1, 0, b.tcount, P, N, b.mask, b.best_pose, b.refit_pose, b.refit_status, st);
     if (rc) return rc;
     SLAM_HIP_CHECK(hipEventRecord(g_ev[5], st));
     SLAM_HIP_CHECK(hipMemcpyAsync(io->h_pose, b.refit_pose, sizeof(double) * 12 * (size_t)P, hipMemcpyDeviceToHost, st));

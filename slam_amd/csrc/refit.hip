@@ -97,7 +97,8 @@ __device__ __forceinline__ Pose apply_step(const Pose &P, const double (&d)[6]) 
 
 constexpr int MAX_EVAL = 60;
 
-__global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, const float4 *xy1, const int *count,
+template <typename XY4>
+__global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, const XY4 *xy1, const int *count,
                                                    int seg_stride, const unsigned long long *mask_words,
                                                    const double *pose0, double *pose_out, uint8_t *status) {
     const int seg = blockIdx.x, lane = threadIdx.x;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
     const int words = seg_stride / 64;
     const unsigned long long *mw = mask_words + (size_t)seg * words;
     const double *Xs = X + (size_t)seg * seg_stride * 3;
-    const float4 *obs = xy1 + (size_t)seg * seg_stride;
+    const XY4 *obs = xy1 + (size_t)seg * seg_stride;
     const double fx = K.m[0], fy = K.m[4], cx = K.m[2], cy = K.m[5];
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
 
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
                 const double xc = Q.R[0][0] * x + Q.R[0][1] * y + Q.R[0][2] * z + Q.t[0];
                 const double yc = Q.R[1][0] * x + Q.R[1][1] * y + Q.R[1][2] * z + Q.t[1];
                 const double zc = Q.R[2][0] * x + Q.R[2][1] * y + Q.R[2][2] * z + Q.t[2];
-                const float4 o = obs[i];
+                const XY4 o = obs[i];
                 const double ru = fx * xc / zc + cx - (double)o.x, rv = fy * yc / zc + cy - (double)o.y;
                 c += ru * ru + rv * rv;
             }
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
                 const double yc = P.R[1][0] * x + P.R[1][1] * y + P.R[1][2] * z + P.t[1];
                 const double zc = P.R[2][0] * x + P.R[2][1] * y + P.R[2][2] * z + P.t[2];
                 const double iz = 1.0 / zc;
-                const float4 o = obs[i];
+                const XY4 o = obs[i];
                 const double ru = fx * xc * iz + cx - (double)o.x, rv = fy * yc * iz + cy - (double)o.y;
                 // d(u,v)/dXc
                 const double ux = fx * iz, uz = -fx * xc * iz * iz, vy = fy * iz, vz = -fy * yc * iz * iz;
@@ -238,24 +239,28 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
 
 }  // namespace
 
-int slam_launch_refit(const Mat33 &K, const double *d_X, const float *d_xy1, const int32_t *d_count, int n_seg,
+int slam_launch_refit(const Mat33 &K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count, int n_seg,
                       int seg_stride, const uint64_t *d_mask_words, const double *d_pose0, double *d_pose,
                       uint8_t *d_status, hipStream_t st) {
     if (n_seg <= 0) return SLAM_OK;
     SLAM_REQUIRE(seg_stride % 64 == 0, "slam_refit_pnp: seg_stride must be a multiple of 64");
-    hipLaunchKernelGGL(refit_kernel, dim3(n_seg), dim3(64), 0, st, K, d_X, (const float4 *)d_xy1, d_count, seg_stride,
-                       (const unsigned long long *)d_mask_words, d_pose0, d_pose, d_status);
+    if (xy_f64)
+        hipLaunchKernelGGL(refit_kernel<double4>, dim3(n_seg), dim3(64), 0, st, K, d_X, (const double4 *)d_xy1, d_count,
+                           seg_stride, (const unsigned long long *)d_mask_words, d_pose0, d_pose, d_status);
+    else
+        hipLaunchKernelGGL(refit_kernel<float4>, dim3(n_seg), dim3(64), 0, st, K, d_X, (const float4 *)d_xy1, d_count,
+                           seg_stride, (const unsigned long long *)d_mask_words, d_pose0, d_pose, d_status);
     SLAM_HIP_CHECK(hipGetLastError());
     return SLAM_OK;
 }
 
-extern "C" int slam_refit_pnp(const double *h_K, const double *d_X, const float *d_xy1, const int32_t *d_count,
+extern "C" int slam_refit_pnp(const double *h_K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count,
                               int n_seg, int seg_stride, const uint64_t *d_mask_words, const double *d_pose0,
                               double *d_pose, uint8_t *d_status, void *stream) {
     SLAM_REQUIRE(h_K && d_X && d_xy1 && d_count && d_mask_words && d_pose0 && d_pose && d_status,
                  "slam_refit_pnp: null pointer");
     Mat33 K;
     for (int i = 0; i < 9; ++i) K.m[i] = h_K[i];
-    return slam_launch_refit(K, d_X, d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status,
+    return slam_launch_refit(K, d_X, d_xy1, xy_f64, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status,
                              (hipStream_t)stream);
 }

@@ -51,7 +51,8 @@ __device__ __forceinline__ bool within(const double *P, double x, double y, doub
 
 constexpr int SB = 256;   // 4 waves = 4 hypotheses of the same segment per workgroup (shared L1 footprint)
 
-__global__ __launch_bounds__(SB) void score_kernel(Mat33 K, Mat34 M2, const double *X, const float4 *xy1,
+template <typename XY4>
+__global__ __launch_bounds__(SB) void score_kernel(Mat33 K, Mat34 M2, const double *X, const XY4 *xy1,
                                                    const int *count, const int *seg_of, int seg_stride,
                                                    const double *pose, const uint8_t *status, int n_hyp, double thr,
                                                    int *inlier_count, unsigned long long *mask) {
@@ -74,14 +75,14 @@ __global__ __launch_bounds__(SB) void score_kernel(Mat33 K, Mat34 M2, const doub
     gemm_33_34(K.m, Tr, Pr);
 
     const double *Xs = X + (size_t)seg * seg_stride * 3;
-    const float4 *obs = xy1 + (size_t)seg * seg_stride;
+    const XY4 *obs = xy1 + (size_t)seg * seg_stride;
     int total = 0;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         bool ok = false;
         if (live && i < n) {
             const double x = Xs[i * 3 + 0], y = Xs[i * 3 + 1], z = Xs[i * 3 + 2];
-            const float4 c = obs[i];
+            const XY4 c = obs[i];
             ok = within(Pl, x, y, z, (double)c.x, (double)c.y, thr) && within(Pr, x, y, z, (double)c.z, (double)c.w, thr);
         }
         const unsigned long long bal = __ballot(ok);
@@ -111,22 +112,28 @@ __global__ __launch_bounds__(256) void consensus_f64_kernel(Mat33 K, Mat34 M2, M
 
 }  // namespace
 
-int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const float *d_xy1, const int32_t *d_count,
+int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const void *d_xy1, int xy_f64,
+                      const int32_t *d_count,
                       const int32_t *d_seg_of, int n_rows, int seg_stride, const double *d_pose,
                       const uint8_t *d_status, int n_hyp, double thr, int32_t *d_inlier_count, uint64_t *d_mask,
                       hipStream_t st) {
     if (n_rows <= 0 || n_hyp <= 0) return SLAM_OK;
     SLAM_REQUIRE(n_rows <= 65535, "slam_score_hypotheses: more than 65535 segments per call");
     SLAM_REQUIRE(!d_mask || seg_stride % 64 == 0, "slam_score_hypotheses: seg_stride must be a multiple of 64 for masks");
-    hipLaunchKernelGGL(score_kernel, dim3(slam_div_up(n_hyp, SB / 64), n_rows), dim3(SB), 0, st, K, M2, d_X,
-                       (const float4 *)d_xy1, d_count, d_seg_of, seg_stride, d_pose, d_status, n_hyp, thr,
-                       d_inlier_count, (unsigned long long *)d_mask);
+    if (xy_f64)
+        hipLaunchKernelGGL(score_kernel<double4>, dim3(slam_div_up(n_hyp, SB / 64), n_rows), dim3(SB), 0, st, K, M2, d_X,
+                           (const double4 *)d_xy1, d_count, d_seg_of, seg_stride, d_pose, d_status, n_hyp, thr,
+                           d_inlier_count, (unsigned long long *)d_mask);
+    else
+        hipLaunchKernelGGL(score_kernel<float4>, dim3(slam_div_up(n_hyp, SB / 64), n_rows), dim3(SB), 0, st, K, M2, d_X,
+                           (const float4 *)d_xy1, d_count, d_seg_of, seg_stride, d_pose, d_status, n_hyp, thr,
+                           d_inlier_count, (unsigned long long *)d_mask);
     SLAM_HIP_CHECK(hipGetLastError());
     return SLAM_OK;
 }
 
-extern "C" int slam_score_hypotheses(const double *h_K, const double *h_M2, const double *d_X, const float *d_xy1,
-                                     const int32_t *d_count, int n_seg, int seg_stride, const double *d_pose,
+extern "C" int slam_score_hypotheses(const double *h_K, const double *h_M2, const double *d_X, const void *d_xy1,
+                                     int xy_f64, const int32_t *d_count, int n_seg, int seg_stride, const double *d_pose,
                                      const uint8_t *d_status, int n_hyp, double thr, int32_t *d_inlier_count,
                                      uint64_t *d_mask, void *stream) {
     SLAM_REQUIRE(h_K && h_M2 && d_X && d_xy1 && d_count && d_pose && d_status && d_inlier_count,
@@ -135,7 +142,7 @@ extern "C" int slam_score_hypotheses(const double *h_K, const double *h_M2, cons
     Mat34 M2;
     for (int i = 0; i < 9; ++i) K.m[i] = h_K[i];
     for (int i = 0; i < 12; ++i) M2.m[i] = h_M2[i];
-    return slam_launch_score(K, M2, d_X, d_xy1, d_count, nullptr, n_seg, seg_stride, d_pose, d_status, n_hyp, thr,
+    return slam_launch_score(K, M2, d_X, d_xy1, xy_f64, d_count, nullptr, n_seg, seg_stride, d_pose, d_status, n_hyp, thr,
                              d_inlier_count, d_mask, (hipStream_t)stream);
 }
 

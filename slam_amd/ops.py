@@ -43,6 +43,14 @@ def _f64(a, shape) -> np.ndarray:
     return out
 
 
+def _xy_f64(xy1: torch.Tensor) -> int:
+    if xy1.dtype == torch.float64:
+        return 1
+    if xy1.dtype == torch.float32:
+        return 0
+    raise TypeError("observations must be float32 or float64")
+
+
 def device() -> torch.device:
     if not torch.cuda.is_available():
         raise RuntimeError("slam_amd needs a HIP device (MI355X); none is visible")
@@ -159,7 +167,7 @@ def p3p_hypotheses(K, X, xy1, count, sample):
     n_hyp = sample.shape[1]
     pose = torch.empty((n_seg, n_hyp, 3, 4), dtype=torch.float64, device=X.device)
     status = torch.empty((n_seg, n_hyp), dtype=torch.uint8, device=X.device)
-    check(_lib.lib().slam_p3p_hypotheses(_host(K), _dev(X, torch.float64), _dev(xy1, torch.float32),
+    check(_lib.lib().slam_p3p_hypotheses(_host(K), _dev(X, torch.float64), _dev(xy1), _xy_f64(xy1),
                                          _dev(count, torch.int32), n_seg, stride, _dev(sample, torch.int32), n_hyp,
                                          _dev(pose), _dev(status), _stream()))
     return pose, status
@@ -171,7 +179,7 @@ def score_hypotheses(K, M2, X, xy1, count, pose, status, thr=4.0, want_mask=Fals
     n_hyp = pose.shape[1]
     cnt = torch.empty((n_seg, n_hyp), dtype=torch.int32, device=X.device)
     mask = torch.zeros((n_seg, n_hyp, stride // 64), dtype=torch.int64, device=X.device) if want_mask else None
-    check(_lib.lib().slam_score_hypotheses(_host(K), _host(M2), _dev(X, torch.float64), _dev(xy1, torch.float32),
+    check(_lib.lib().slam_score_hypotheses(_host(K), _host(M2), _dev(X, torch.float64), _dev(xy1), _xy_f64(xy1),
                                            _dev(count, torch.int32), n_seg, stride, _dev(pose, torch.float64),
                                            _dev(status, torch.uint8), n_hyp, float(thr), _dev(cnt),
                                            _dev(mask) if mask is not None else None, _stream()))
@@ -193,7 +201,7 @@ def refit_pnp(K, X, xy1, count, mask_words, pose0):
     n_seg, stride, _ = X.shape
     pose = torch.empty((n_seg, 3, 4), dtype=torch.float64, device=X.device)
     status = torch.empty(n_seg, dtype=torch.uint8, device=X.device)
-    check(_lib.lib().slam_refit_pnp(_host(K), _dev(X, torch.float64), _dev(xy1, torch.float32), _dev(count, torch.int32),
+    check(_lib.lib().slam_refit_pnp(_host(K), _dev(X, torch.float64), _dev(xy1), _xy_f64(xy1), _dev(count, torch.int32),
                                     n_seg, stride, _dev(mask_words, torch.int64), _dev(pose0, torch.float64), _dev(pose),
                                     _dev(status), _stream()))
     return pose, status

@@ -1,0 +1,298 @@
+"""Plain-Python types that cross the hot-path boundary, with the reference's signatures.
+
+* `DMatch` / `KeyPoint`: duck types of cv2.DMatch / cv2.KeyPoint.  The reference reads only
+  `.queryIdx/.trainIdx/.distance` (utils/utills.py:69,147,161-162,433,453-454,969) and `.pt` (:163-164).
+  They are classes with __slots__, NOT tuples: `np.array(matches)` (utills.py:110) must stay a 1-D object array.
+* `Feature` (DataBaseDirectory/Feature.py:3-39), `Frame` (Frame.py:5-58), `Track` (Trck.py:5-105),
+  `DataBase` (DataBase.py:37-328): same constructors and accessors, re-implemented; they hold only Python/numpy
+  values, so a DataBase pickles exactly like the reference's (DataBase.py:15-34).
+"""
+from __future__ import annotations
+
+import bisect
+import pickle
+import random
+
+import numpy as np
+
+from .synth import K_KITTI
+
+
+class DMatch:
+    __slots__ = ("queryIdx", "trainIdx", "imgIdx", "distance")
+
+    def __init__(self, queryIdx=-1, trainIdx=-1, distance=float("inf"), imgIdx=0):
+        self.queryIdx = int(queryIdx)
+        self.trainIdx = int(trainIdx)
+        self.imgIdx = int(imgIdx)
+        self.distance = float(distance)
+
+    def __repr__(self):
+        return f"DMatch(queryIdx={self.queryIdx}, trainIdx={self.trainIdx}, distance={self.distance})"
+
+    def __getstate__(self):
+        return (self.queryIdx, self.trainIdx, self.imgIdx, self.distance)
+
+    def __setstate__(self, s):
+        self.queryIdx, self.trainIdx, self.imgIdx, self.distance = s
+
+
+class KeyPoint:
+    __slots__ = ("pt",)
+
+    def __init__(self, x, y):
+        self.pt = (float(np.float32(x)), float(np.float32(y)))     # cv2 stores float32, returns Python floats
+
+    def __repr__(self):
+        return f"KeyPoint{self.pt}"
+
+    def __getstate__(self):
+        return self.pt
+
+    def __setstate__(self, s):
+        self.pt = s
+
+
+def keypoints_from_xy(xy) -> np.ndarray:
+    """float[n, 2] -> object array of KeyPoint (what np.array(alg.detectAndCompute(...)[0]) yields, utills.py:54)."""
+    out = np.empty(len(xy), dtype=object)
+    for i, (x, y) in enumerate(xy):
+        out[i] = KeyPoint(x, y)
+    return out
+
+
+def keypoints_to_xy(kpts) -> np.ndarray:
+    """object array / list of things with `.pt` -> float32[n, 2]."""
+    out = np.empty((len(kpts), 2), np.float32)
+    for i, k in enumerate(kpts):
+        out[i, 0], out[i, 1] = k.pt
+    return out
+
+
+def dmatches_from_arrays(q, t, d) -> np.ndarray:
+    out = np.empty(len(q), dtype=object)
+    for i in range(len(q)):
+        out[i] = DMatch(q[i], t[i], d[i])
+    return out
+
+
+class Feature:
+    """A feature of a stereo frame: key-point indices and pixel coordinates in the left and right image."""
+    __slots__ = ("_kl", "_kr", "_xl", "_xr", "_yl", "_yr")
+
+    def __init__(self, kpt_left_idx, kpt_right_idx, x_left, x_right, y_left, y_right):
+        self._kl, self._kr = kpt_left_idx, kpt_right_idx
+        self._xl, self._xr, self._yl, self._yr = x_left, x_right, y_left, y_right
+
+    def get_left_coor(self):
+        return self._xl, self._yl
+
+    def get_right_coor(self):
+        return self._xr, self._yr
+
+    def get_left_kpt(self):
+        return self._kl
+
+    def get_right_kpt(self):
+        return self._kr
+
+    def __getstate__(self):
+        return (self._kl, self._kr, self._xl, self._xr, self._yl, self._yr)
+
+    def __setstate__(self, s):
+        self._kl, self._kr, self._xl, self._xr, self._yl, self._yr = s
+
+
+class Frame:
+    """A frame: id, the ids of the tracks seen in it, global extrinsic [R|t], calibration, camera centre."""
+
+    def __init__(self, id, ex_cam_mat, calib_cam_mat=K_KITTI):
+        self._id = id
+        self._tracks = []
+        self._ex = ex_cam_mat
+        self._calib = calib_cam_mat
+        self._pose = self.compute_pose(ex_cam_mat)
+
+    def add_track(self, track_id):
+        self._tracks.append(track_id)
+
+    def get_id(self):
+        return self._id
+
+    def get_tracks_ids(self):
+        return np.array(self._tracks).astype(int)
+
+    def get_tracks_num(self):
+        return len(self._tracks)
+
+    def get_ex_cam_mat(self):
+        return self._ex
+
+    def get_calib_cam_mat(self):
+        return self._calib
+
+    def get_pose(self):
+        return self._pose
+
+    def compute_pose(self, ex_cam_mat):
+        """Camera centre in world coordinates: -R^T t (Frame.py:50-58)."""
+        return -1 * ex_cam_mat[:, :3].T @ ex_cam_mat[:, 3]
+
+
+class Track:
+    """A landmark track: {frame id -> Feature} plus the sorted frame ids."""
+
+    def __init__(self, track_id):
+        self._id = track_id
+        self._by_frame = {}
+        self._sorted_ids = []
+
+    def get_id(self):
+        return self._id
+
+    def add_feature(self, frame_id, feature):
+        self._by_frame[frame_id] = feature
+        bisect.insort(self._sorted_ids, frame_id)
+
+    def get_frames_ids(self):
+        return np.array(list(self._by_frame.keys())).astype(int)
+
+    def get_feature_at_frame(self, frame_id):
+        return self._by_frame[frame_id]
+
+    def get_left_locations_in_all_frames(self):
+        return [self._by_frame[f].get_left_coor() for f in self._sorted_ids]
+
+    def get_left_locations_in_specific_frames(self, frames_ind):
+        return [self._by_frame[f].get_left_coor() for f in frames_ind]
+
+    def get_right_locations_in_all_frames(self):
+        return [self._by_frame[f].get_right_coor() for f in self._sorted_ids]
+
+    def get_right_locations_in_specific_frames(self, frames_ind):
+        return [self._by_frame[f].get_right_coor() for f in frames_ind]
+
+    def get_frames_features_dict(self):
+        return self._by_frame
+
+    def get_track_len(self):
+        return len(self._by_frame)
+
+    def get_last_frame_ind(self):
+        return self._sorted_ids[-1]
+
+    def get_first_frame_ind(self):
+        return self._sorted_ids[0]
+
+
+def save(path, db):
+    """DataBase.py:15-22."""
+    with open(path, "wb") as fh:
+        pickle.dump(db, fh)
+
+
+def load(saved_db_path):
+    """DataBase.py:25-34."""
+    with open(saved_db_path, "rb") as fh:
+        return pickle.load(fh)
+
+
+class DataBase:
+    """Track database built from the per-pair supporter features of the hot path (DataBase.py:37-153).
+
+    Tracks are chained on the LEFT key-point index: a supporter of pair (i, i+1) whose frame-i left key-point
+    ended a track in pair (i-1, i) extends that track; otherwise it opens a new one.  Track ids are assigned in
+    encounter order, which is the order of the features inside each pair (ascending left key-point of frame i)."""
+
+    def __init__(self, prev_and_next_frame_features, inliers_percentage, global_cam_trans, relative_cam_trans):
+        self._tracks = []
+        self._frames = []
+        self._last_kpts = {}
+        self._inliers_percentage = inliers_percentage
+        self._pair_features = prev_and_next_frame_features
+        self._relative = np.array(relative_cam_trans)
+        self.create_db(prev_and_next_frame_features, global_cam_trans)
+
+    def create_db(self, prev_and_next_frame_features, global_cam_trans):
+        self.add_frame(Frame(0, global_cam_trans[0]))
+        for i, (cur, nxt) in enumerate(prev_and_next_frame_features):
+            self.set_tracks_and_frames(cur, nxt, i, global_cam_trans)
+        self._frames = np.array(self._frames)
+        self._tracks = np.array(self._tracks)
+
+    def set_tracks_and_frames(self, first_frame_features_obj, second_frame_features_obj, first_frame_id, global_trans):
+        second = first_frame_id + 1
+        self.add_frame(Frame(second, global_trans[second]))
+        self._last_kpts = self.find_tracks_between_consecutive_frame(first_frame_features_obj,
+                                                                     second_frame_features_obj, first_frame_id, second)
+
+    def find_tracks_between_consecutive_frame(self, first_frame_features_obj, second_frame_features_obj,
+                                              first_frame_id, second_frame_id):
+        carried = {}
+        f_first, f_second = self._frames[first_frame_id], self._frames[second_frame_id]
+        for feat0, feat1 in zip(first_frame_features_obj, second_frame_features_obj):
+            tid = self._last_kpts.get(feat0.get_left_kpt())
+            if tid is None:
+                tid = len(self._tracks)
+                track = Track(tid)
+                self.add_track(track)
+                track.add_feature(first_frame_id, feat0)
+                f_first.add_track(tid)
+            else:
+                track = self._tracks[tid]
+            track.add_feature(second_frame_id, feat1)
+            f_second.add_track(tid)
+            carried[feat1.get_left_kpt()] = tid
+        return carried
+
+    def add_frame(self, frame):
+        self._frames.append(frame)
+
+    def add_track(self, track):
+        self._tracks.append(track)
+
+    def get_track_features_in_frame(self, frame_id, track_id):
+        return self._tracks[track_id].get_feature_at_frame(frame_id)
+
+    def get_num_tracks(self):
+        return len(self._tracks)
+
+    def get_num_frames(self):
+        return len(self._frames)
+
+    def get_tracks(self):
+        return self._tracks
+
+    def get_tracks_at_frame(self, frames_id):
+        return self._tracks[self._frames[frames_id].get_tracks_ids()]
+
+    def get_frames_at_track(self, track_id):
+        return self._frames[self._tracks[track_id].get_frames_ids()]
+
+    def get_frames(self):
+        return self._frames
+
+    def get_inliers_percentage_per_frame(self):
+        return self._inliers_percentage
+
+    def get_prev_and_next_frame_features(self):
+        return self._pair_features
+
+    def get_rand_track(self, track_len):
+        while True:
+            t = self._tracks[random.randint(0, len(self._tracks) - 1)]
+            if t.get_track_len() == track_len:
+                return t
+
+    def get_relative_cam_trans(self):
+        return self._relative
+
+    def initial_estimate_poses(self):
+        return np.array([f.get_pose() for f in self._frames])
+
+    def get_tracks_with_specific_len(self, track_len):
+        return self._tracks[[t.get_track_len() == track_len for t in self._tracks]]
+
+    def tracks_median_len(self, percentage):
+        lens = sorted(t.get_track_len() for t in self._tracks)
+        return lens[int(percentage * len(lens))]

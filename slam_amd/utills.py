@@ -1,0 +1,601 @@
+"""Drop-in for the hot-path functions of the reference's `utils/utills.py`, running on the MI355X.
+
+Same names, positional signatures, return types and error behaviour as the reference (line numbers below refer to
+/root/reference/utils/utills.py); the arithmetic runs in the HIP kernels behind libslam_amd.so.  What stays on the
+host is container glue the reference also does in Python (dicts, object arrays, list filtering) and the control flow
+of the adaptive RANSAC loop, which is replayed over batched device results.
+
+Differences a caller can observe, all forced by the environment:
+  * detection (cv2 AKAZE, :46-54) is out of scope: frames come from a detection source installed with
+    `set_detection_source` (anything with `get(frame_num) -> (xy_left, dsc_left, xy_right, dsc_right)`);
+  * `cv2.DMatch` / `cv2.KeyPoint` are replaced by the duck types of slam_amd.types;
+  * the whole-movie and loop-closure drivers batch all frame pairs into one device pass, so they give every pair its
+    own MT19937 stream (seeds drawn once from the global np.random state) instead of threading one global stream
+    through the pairs sequentially; the per-pair functions consume the global stream exactly like the reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib, ops, pipeline
+from .config import BRUTE_FORCE, FLANN_KNN, NORM_HAMMING, NORM_HAMMING2, REGULAR_KNN, HotPathConfig
+from .synth import K_KITTI, M1_KITTI, M2_KITTI
+from .types import (DataBase, DMatch, Feature, Frame, KeyPoint, Track, dmatches_from_arrays, keypoints_from_xy,
+                    keypoints_to_xy)
+
+# == module constants, as utills.py:17-42 ==
+K, M1, M2 = K_KITTI.copy(), M1_KITTI.copy(), M2_KITTI.copy()
+RATIO = 0.6
+MATCHES_NORM = NORM_HAMMING2
+MATCH_METHOD = BRUTE_FORCE
+PNP_NUM_PTS = 4
+SUPP_ERR = 2
+REC_ERR = 2
+MOVIE_LEN = 3450
+IMAGE_HEIGHT, IMAGE_WIDTH = 376, 1241
+SOLVEPNP_ITERATIVE, SOLVEPNP_AP3P = 0, 5        # cv2 flag values (:503, :563)
+MAX_DRAWS = 64000                               # bound on the reference's unbounded retry loop (:506-507)
+
+DETECTIONS = None
+
+
+def set_detection_source(src):
+    """Installs the object that stands in for KITTI.get_image + ALG.detectAndCompute (:52-53, :393)."""
+    global DETECTIONS
+    DETECTIONS = src
+
+
+class ArrayDetections:
+    """Detection source over stacked arrays: desc uint8[F,2,n_max,>=61], xy float32[F,2,n_max,2], count int32[F,2]."""
+
+    def __init__(self, desc, xy, count):
+        self.desc, self.xy, self.count = desc, xy, count
+
+    def __len__(self):
+        return len(self.count)
+
+    def get(self, i):
+        n0, n1 = self.count[i]
+        return self.xy[i, 0, :n0], self.desc[i, 0, :n0, :61], self.xy[i, 1, :n1], self.desc[i, 1, :n1, :61]
+
+    def arrays(self, frames):
+        frames = np.asarray(frames)
+        d = np.zeros((len(frames), 2, self.desc.shape[2], 64), np.uint8)
+        d[..., :self.desc.shape[3]] = self.desc[frames]
+        return d, np.ascontiguousarray(self.xy[frames]), np.ascontiguousarray(self.count[frames])
+
+
+def _cuda(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(ops.device())
+
+
+# == Ex1: matching ==
+def _match_arrays(img1_dsc, img2_dsc, norm, mode):
+    q = _cuda(ops.pad_descriptors(img1_dsc))
+    t = _cuda(ops.pad_descriptors(img2_dsc))
+    k1, k2 = ops.match_keys(q, t, norm, mode)
+    i1, d1 = (x.cpu().numpy() for x in ops.unpack_keys(k1))
+    if k2 is None:
+        return i1, d1, None, None
+    i2, d2 = (x.cpu().numpy() for x in ops.unpack_keys(k2))
+    return i1, d1, i2, d2
+
+
+def bf_matching(metric, img1_dsc, img2_dsc, crossCheck=True, sort=True):
+    """:57-70.  cv2.BFMatcher(metric, crossCheck).match: list of DMatch in query order, or sorted by distance."""
+    if crossCheck:
+        idx, dist, _, _ = _match_arrays(img1_dsc, img2_dsc, metric, _lib.SLAM_MATCH_CROSSCHECK)
+    else:
+        if len(img2_dsc) == 0:
+            return []
+        idx, dist, _, _ = _match_arrays(img1_dsc, img2_dsc, metric, _lib.SLAM_MATCH_KNN2)
+    q = np.nonzero(idx >= 0)[0]
+    matches = list(dmatches_from_arrays(q, idx[q], dist[q]))
+    if sort:
+        matches = sorted(matches, key=lambda x: x.distance)
+    return matches
+
+
+def knn_matching(metric, img1_dsc, img2_dsc):
+    """:92-102.  cv2.BFMatcher(metric).knnMatch(d1, d2, 2): per query the two nearest train rows."""
+    i1, d1, i2, d2 = _match_arrays(img1_dsc, img2_dsc, metric, _lib.SLAM_MATCH_KNN2)
+    out = []
+    for q in range(len(i1)):
+        row = [DMatch(q, i1[q], d1[q])] if i1[q] >= 0 else []
+        if i2[q] >= 0:
+            row.append(DMatch(q, i2[q], d2[q]))
+        out.append(row)
+    return out
+
+
+def knn_flann_matching(img1_dsc, img2_dsc):
+    """:73-89 uses an approximate, randomised LSH index (cv2.FlannBasedMatcher): out of scope."""
+    raise NotImplementedError("FLANN-LSH matching is approximate and non-deterministic; use BRUTE_FORCE or REGULAR_KNN")
+
+
+def significance_test(matches, ratio):
+    """:131-152."""
+    pass_test, failed_test = [], []
+    for first, second in matches:
+        (pass_test if first.distance < ratio * second.distance else failed_test).append(first)
+    return pass_test, failed_test
+
+
+def match(img1_dsc, img2_dsc, method=MATCH_METHOD):
+    """:105-119.  Default: cross-check brute force under MATCHES_NORM, unsorted, as a numpy object array."""
+    if method == BRUTE_FORCE:
+        return np.array(bf_matching(MATCHES_NORM, img1_dsc, img2_dsc, sort=False), dtype=object)
+    if method == REGULAR_KNN:
+        matches = knn_matching(MATCHES_NORM, img1_dsc, img2_dsc)
+    elif method == FLANN_KNN:
+        matches = knn_flann_matching(img1_dsc, img2_dsc)
+    else:
+        matches = []
+    matches, _ = significance_test(matches, RATIO)
+    return np.array(matches, dtype=object)
+
+
+def detect_and_match(img1, img2):
+    """:122-128 with detection replaced by the detection source: img = (xy, dsc)."""
+    (xy1, dsc1), (xy2, dsc2) = img1, img2
+    return keypoints_from_xy(xy1), np.array(dsc1), keypoints_from_xy(xy2), np.array(dsc2), match(dsc1, dsc2)
+
+
+# == Ex2: stereo-row rejection, triangulation ==
+def axes_of_matches(match, img1_kpts, img2_kpts):
+    """:157-165."""
+    x1, y1 = img1_kpts[match.queryIdx].pt
+    x2, y2 = img2_kpts[match.trainIdx].pt
+    return x1, y1, x2, y2
+
+
+def rectified_stereo_pattern_rej(img1_kpts, img2_kpts, matches):
+    """:168-183.  |y_right - y_left| <= REC_ERR, inclusive; returns index lists into `matches`."""
+    inl, outl = [], []
+    for i in range(len(matches)):
+        _, y1, _, y2 = axes_of_matches(matches[i], img1_kpts, img2_kpts)
+        (inl if abs(y2 - y1) <= REC_ERR else outl).append(i)
+    return inl, outl
+
+
+def get_matches_coor(matches, img1_kpts, img2_kpts):
+    """:186-196."""
+    a = [img1_kpts[m.queryIdx].pt for m in matches]
+    b = [img2_kpts[m.trainIdx].pt for m in matches]
+    return np.array(a), np.array(b)
+
+
+def triangulate(l_mat, r_mat, kp1_xy_lst, kp2_xy_lst):
+    """:242-255.  float64[n, 3] world points by linear (DLT) triangulation."""
+    a = np.asarray(kp1_xy_lst, dtype=np.float64).reshape(-1, 2)
+    b = np.asarray(kp2_xy_lst, dtype=np.float64).reshape(-1, 2)
+    if len(a) == 0:
+        return np.array([])
+    return ops.triangulate_f64(l_mat, r_mat, _cuda(a), _cuda(b)).cpu().numpy()
+
+
+def linear_least_square(l_cam_mat, r_cam_mat, kp1_xy, kp2_xy):
+    """:220-239.  Unit homogeneous solution of the 4x4 DLT system (sign is arbitrary, as with an SVD)."""
+    X = triangulate(l_cam_mat, r_cam_mat, [kp1_xy], [kp2_xy])[0]
+    v = np.append(X, 1.0)
+    return v / np.linalg.norm(v)
+
+
+# == Ex3: 4-view join, RANSAC ==
+def create_rec_dic(pair_matches, pair_rec_matches_idx):
+    """:423-435."""
+    return {pair_matches[idx].queryIdx: idx for idx in pair_rec_matches_idx}
+
+
+def find_kpts_in_all_4_rec(left0_left1_matches, rec0_dic, rec1_dic):
+    """:438-471."""
+    q0, q1, q01 = [], [], []
+    for i, m in enumerate(left0_left1_matches):
+        if m.queryIdx in rec0_dic and m.trainIdx in rec1_dic:
+            q0.append(rec0_dic[m.queryIdx])
+            q1.append(rec1_dic[m.trainIdx])
+            q01.append(i)
+    return q0, q1, q01
+
+
+def tracking_4images(left0_dsc, left1_dsc, pair0_matches, pair0_rec_matches_idx, pair1_matches, pair1_rec_matches_idx):
+    """:945-960."""
+    left0_left1_matches = match(left0_dsc, left1_dsc)
+    rec0 = create_rec_dic(pair0_matches, pair0_rec_matches_idx)
+    rec1 = create_rec_dic(pair1_matches, pair1_rec_matches_idx)
+    i0, i1, _ = find_kpts_in_all_4_rec(left0_left1_matches, rec0, rec1)
+    return np.asarray(pair0_matches, dtype=object)[i0], np.asarray(pair1_matches, dtype=object)[i1]
+
+
+def compose_transformations(first_ex_mat, second_ex_mat):
+    """:659-669."""
+    hom1 = np.append(first_ex_mat, [np.array([0, 0, 0, 1])], axis=0)
+    return second_ex_mat @ hom1
+
+
+def project(p3d_pts, cam_proj_mat):
+    """:698-705 (host helper; the hot path projects inside the scoring kernel)."""
+    hom = p3d_pts @ cam_proj_mat[:, :3].T + cam_proj_mat[:, 3].T
+    return hom[:, :2] / hom[:, [-1]]
+
+
+def compute_square_dist(pts_lst1, pts_lst2=None, dim="3d"):
+    """:719-736, including the quirk that the default returns the UN-squared norm."""
+    if pts_lst2 is None:
+        pts_lst2 = np.zeros(pts_lst1.shape)
+    sub = pts_lst1 - pts_lst2
+    if dim == "2d":
+        return np.einsum("ij,ij->i", sub, sub)
+    if dim == "3d":
+        return np.linalg.norm(sub, axis=1)
+    return 0
+
+
+def check_projection(img_projected_pts, img_pts_coor, acc=SUPP_ERR):
+    """:708-716."""
+    return compute_square_dist(img_projected_pts, img_pts_coor) <= acc ** 2
+
+
+def _as_f64_points(world, left, right):
+    X = np.ascontiguousarray(np.asarray(world, dtype=np.float64).reshape(-1, 3))
+    l = np.ascontiguousarray(np.asarray(left, dtype=np.float64).reshape(-1, 2))
+    r = np.ascontiguousarray(np.asarray(right, dtype=np.float64).reshape(-1, 2))
+    return X, l, r
+
+
+def consensus_match(calib_mat, left1_ex_mat, right1_to_left1_ex_mat, world_p3d_pts, left1_matches_coor,
+                    right1_matches_coor, acc):
+    """:533-545.  bool[n]: projection within acc**2 px (un-squared distance) in left1 AND right1."""
+    X, l, r = _as_f64_points(world_p3d_pts, left1_matches_coor, right1_matches_coor)
+    if len(X) == 0:
+        return np.zeros(0, bool)
+    m = ops.consensus_match_f64(calib_mat, right1_to_left1_ex_mat, left1_ex_mat, _cuda(X), _cuda(l), _cuda(r), acc ** 2)
+    return m.cpu().numpy().astype(bool)
+
+
+def find_supporters_4_frame(pair0_p3d_pts, left1_proj_mat, left1_matches_coor, right1_proj_mat, right1_matches_coor,
+                            acc=SUPP_ERR):
+    """:672-695 (host helper on ready-made projection matrices)."""
+    return check_projection(project(pair0_p3d_pts, left1_proj_mat), left1_matches_coor, acc) & \
+        check_projection(project(pair0_p3d_pts, right1_proj_mat), right1_matches_coor, acc)
+
+
+class _Device4View:
+    """Points of one frame pair on the device in the batched layout (one segment, float64 observations)."""
+
+    def __init__(self, world, left1, right1):
+        X, l, r = _as_f64_points(world, left1, right1)
+        self.n = len(X)
+        self.stride = max(64, (self.n + 63) // 64 * 64)
+        Xs = np.zeros((1, self.stride, 3))
+        Xs[0, :self.n] = X
+        xy = np.zeros((1, self.stride, 4))
+        xy[0, :self.n, :2] = l
+        xy[0, :self.n, 2:] = r
+        self.X, self.xy = _cuda(Xs), _cuda(xy)
+        self.count = _cuda(np.array([self.n], np.int32))
+
+
+def _iter_estimate(prob, outliers_perc, model_parm_num):
+    """:488-489."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.log(1 - prob) / np.log(1 - np.power(1 - outliers_perc, model_parm_num))
+
+
+def online_est_pnp_ransac(model_parm_num, world_p3d_pts, left0_ex_mat, left0_matches_coor, right0_ex_mat,
+                          right0_matches_coor, left1_matches_coor, right1_to_left1_ex_mat, right1_matches_coor,
+                          calib_mat=K, acc=SUPP_ERR):
+    """:474-530.  Adaptive PnP-RANSAC; returns (refit pose | None, PRE-refit best supporter mask).
+
+    Draws come from the global np.random stream exactly as in the reference (4 indices per draw, failed solves
+    consume a draw without counting as an iteration).  Hypotheses are generated and scored on the device in chunks;
+    the stopping rule is replayed over the chunk and the stream is rewound to what the reference would have used."""
+    if model_parm_num != PNP_NUM_PTS:
+        raise NotImplementedError("the minimal solver is P4P/AP3P (PNP_NUM_PTS = 4)")
+    n = len(left1_matches_coor)
+    if n == 0:
+        np.random.randint(0, 0, model_parm_num)                 # raises ValueError like the reference (:502)
+    pts = _Device4View(world_p3d_pts, left1_matches_coor, right1_matches_coor)
+    thr = acc ** 2
+    state = np.random.get_state()
+    prob, outliers_perc, max_iterations = 0.9999, 0.99, 1e3
+    it = draws = inl = outl = 0
+    max_supp, best_pose = -1, None
+    chunk, done = 64, False
+    while not done:
+        sample = np.random.randint(0, n, (chunk, model_parm_num)).astype(np.int32)
+        pose, status = ops.p3p_hypotheses(calib_mat, pts.X, pts.xy, pts.count, _cuda(sample[None]))
+        cnt, _ = ops.score_hypotheses(calib_mat, right1_to_left1_ex_mat, pts.X, pts.xy, pts.count, pose, status, thr)
+        status, cnt = status.cpu().numpy()[0], cnt.cpu().numpy()[0]
+        best_here = -1
+        for k in range(chunk):
+            if not (outliers_perc != 0 and it < _iter_estimate(prob, outliers_perc, model_parm_num)
+                    and it < max_iterations):
+                done = True
+                break
+            if draws >= MAX_DRAWS:
+                raise RuntimeError(f"no PnP-RANSAC termination within {MAX_DRAWS} draws (the reference would not return)")
+            draws += 1
+            if not status[k]:
+                continue                                          # :506-507
+            num = int(cnt[k])
+            if num > max_supp:
+                max_supp, best_here = num, k
+            it += 1
+            outl += n - num
+            inl += num
+            outliers_perc = min(outl / (inl + outl), 0.99)
+        if best_here >= 0:
+            best_pose = pose[0, best_here].clone()
+        chunk = min(chunk * 4, 4096)
+    np.random.set_state(state)                                   # leave the stream where the reference would
+    if draws:
+        np.random.randint(0, n, (draws, model_parm_num))
+    if best_pose is None:
+        raise TypeError("'NoneType' object is not iterable")     # sum(None) in extra_refine (:558)
+    one = torch.ones((1, 1), dtype=torch.uint8, device=pts.X.device)
+    _, words = ops.score_hypotheses(calib_mat, right1_to_left1_ex_mat, pts.X, pts.xy, pts.count, best_pose[None, None],
+                                    one, thr, want_mask=True)
+    mask = ops.mask_words_to_bool(words.cpu().numpy()[0, 0], n)
+    T, status = ops.refit_pnp(calib_mat, pts.X, pts.xy, pts.count, words[0], best_pose[None])
+    return (T.cpu().numpy()[0] if int(status[0]) else None), mask
+
+
+def pnp(world_p3d_pts, img_proj_coor, calib_mat, flag, init=None):
+    """:585-596.  [R|t] 3x4 or None.  flag = SOLVEPNP_AP3P (4 points) or SOLVEPNP_ITERATIVE (>= 6 points; the
+    Levenberg-Marquardt refit starts from `init` or, without one, from the best of a few AP3P poses)."""
+    world = np.asarray(world_p3d_pts, dtype=np.float64).reshape(-1, 3)
+    img = np.asarray(img_proj_coor, dtype=np.float64).reshape(-1, 2)
+    pts = _Device4View(world, img, img)
+    n = pts.n
+    if flag == SOLVEPNP_AP3P:
+        if n != 4:
+            raise ValueError("AP3P needs exactly 4 points")
+        pose, status = ops.p3p_hypotheses(calib_mat, pts.X, pts.xy, pts.count, _cuda(np.arange(4, dtype=np.int32)[None, None]))
+        return pose.cpu().numpy()[0, 0] if int(status[0, 0]) else None
+    if n < 6:
+        return None
+    if init is None:
+        j = np.arange(min(32, n))
+        sample = np.stack([j, (j + n // 4) % n, (j + n // 2) % n, (j + 3 * n // 4) % n], 1).astype(np.int32)
+        pose, status = ops.p3p_hypotheses(calib_mat, pts.X, pts.xy, pts.count, _cuda(sample[None]))
+        cnt, _ = ops.score_hypotheses(calib_mat, M1, pts.X, pts.xy, pts.count, pose, status, float(SUPP_ERR ** 2))
+        cnt = cnt.cpu().numpy()[0] * status.cpu().numpy()[0]
+        if cnt.max() <= 0:
+            return None
+        init_t = pose[0, int(np.argmax(cnt))][None]
+    else:
+        init_t = _cuda(np.asarray(init, dtype=np.float64).reshape(1, 3, 4))
+    words = _cuda(ops.bool_to_mask_words(np.ones((1, n), bool), pts.stride))
+    T, status = ops.refit_pnp(calib_mat, pts.X, pts.xy, pts.count, words, init_t)
+    return T.cpu().numpy()[0] if int(status[0]) else None
+
+
+def extra_refine(supp_indicators, world_p3d_pts, left1_matches_coor, right1_to_left1_ex_mat, right1_matches_coor,
+                 calib_mat=K, acc=SUPP_ERR, it_num=1, init=None):
+    """:548-571."""
+    supp = np.asarray(supp_indicators, dtype=bool)
+    left1_ex_mat, new_mask = None, [False] * len(supp)
+    if supp.sum() < 6:
+        return None, new_mask
+    world, left = np.asarray(world_p3d_pts), np.asarray(left1_matches_coor)
+    for _ in range(it_num):
+        left1_ex_mat = pnp(world[supp], left[supp], calib_mat, SOLVEPNP_ITERATIVE, init=init)
+        if left1_ex_mat is None:
+            continue
+        new_mask = consensus_match(calib_mat, left1_ex_mat, right1_to_left1_ex_mat, world_p3d_pts, left1_matches_coor,
+                                   right1_matches_coor, acc)
+    return left1_ex_mat, new_mask
+
+
+# == poses / trajectory ==
+def relative_camera_pos(ex_cam_mat):
+    """:599-606."""
+    return -1 * ex_cam_mat[:, :3].T @ ex_cam_mat[:, 3]
+
+
+def convert_ex_cam_to_cam_to_world(ex_cam):
+    """:1025-1034."""
+    R, t = ex_cam[:, :3], ex_cam[:, 3]
+    return np.hstack((R.T, (-R.T @ t).reshape(3, 1)))
+
+
+def between(first_cam, second_cam):
+    """:653-656."""
+    return compose_transformations(convert_ex_cam_to_cam_to_world(first_cam), second_cam)
+
+
+def convert_trans_from_rel_to_global(T_arr):
+    """:749-757."""
+    out, last = [], T_arr[0]
+    for t in T_arr:
+        last = compose_transformations(last, t)
+        out.append(last)
+    return out
+
+
+def left_cameras_trajectory(relative_T_arr):
+    """:785-794."""
+    return np.array([relative_camera_pos(t) for t in relative_T_arr])
+
+
+def cameras_rel_pnp_est_and_ground_truth_locations(db, ground_truth=None):
+    """:1200-1208.  Camera-centre offsets between the PnP trajectory and the ground truth (the trajectory-error
+    series the reference plots); `ground_truth` replaces the KITTI poses file (:771-782)."""
+    est = convert_trans_from_rel_to_global(db.get_relative_cam_trans())
+    if ground_truth is None:
+        raise ValueError("pass ground_truth: the KITTI poses file is not available")
+    return left_cameras_trajectory([between(a, b) for a, b in zip(est, ground_truth)])
+
+
+# == Ex4: per-pair and whole-movie drivers ==
+def get_feature_obj(matches, img1_kpts, img2_kpts):
+    """:963-975."""
+    out = np.empty(len(matches), dtype=object)
+    for i, m in enumerate(matches):
+        (x1, y1), (x2, y2) = img1_kpts[m.queryIdx].pt, img2_kpts[m.trainIdx].pt
+        out[i] = Feature(m.queryIdx, m.trainIdx, x1, x2, y1, y2)
+    return out
+
+
+def get_features_left_coor(frame_features):
+    """:978-986."""
+    return np.array([f.get_left_coor() for f in frame_features])
+
+
+def get_features_right_coor(frame_features):
+    """:989-997."""
+    return np.array([f.get_right_coor() for f in frame_features])
+
+
+def read_and_rec_match(frame_num):
+    """:386-396 with detection served by the detection source."""
+    if DETECTIONS is None:
+        raise RuntimeError("no detection source: call slam_amd.utills.set_detection_source(...) first")
+    xy_l, dsc_l, xy_r, dsc_r = DETECTIONS.get(frame_num)
+    l_kpts, l_dsc, r_kpts, _, matches = detect_and_match((xy_l, dsc_l), (xy_r, dsc_r))
+    rec_idx, _ = rectified_stereo_pattern_rej(l_kpts, r_kpts, matches)
+    return l_kpts, l_dsc, r_kpts, matches, rec_idx
+
+
+def find_features_in_consecutive_frames(left0_kpts, left0_dsc, right0_kpts, pair0_matches, pair0_rec_matches_idx,
+                                        left1_kpts, left1_dsc, right1_kpts, pair1_matches, pair1_rec_matches_idx):
+    """:876-925.  -> (pose, frame0 features, frame1 features, inlier %, supporter mask)."""
+    t0, t1 = tracking_4images(left0_dsc, left1_dsc, pair0_matches, pair0_rec_matches_idx, pair1_matches,
+                              pair1_rec_matches_idx)
+    frame0_features = get_feature_obj(t0, left0_kpts, right0_kpts)
+    frame1_features = get_feature_obj(t1, left1_kpts, right1_kpts)
+    left0, right0 = get_features_left_coor(frame0_features), get_features_right_coor(frame0_features)
+    X = triangulate(K @ M1, K @ M2, left0, right0)
+    left1, right1 = get_features_left_coor(frame1_features), get_features_right_coor(frame1_features)
+    trans, mask = online_est_pnp_ransac(PNP_NUM_PTS, X, M1, left0, M2, right0, left1, M2, right1, K, acc=SUPP_ERR)
+    perc = 100 * sum(mask) / len(mask)
+    return trans, frame0_features, frame1_features, perc, mask
+
+
+def compute_trans_between_cur_to_next(left0_kpts, left0_dsc, right0_kpts, pair0_matches, pair0_rec_matches_idx,
+                                      left1_kpts, left1_dsc, right1_kpts, pair1_matches, pair1_rec_matches_idx):
+    """:259-293.  -> (pose, supporter mask)."""
+    trans, _, _, _, mask = find_features_in_consecutive_frames(left0_kpts, left0_dsc, right0_kpts, pair0_matches,
+                                                               pair0_rec_matches_idx, left1_kpts, left1_dsc, right1_kpts,
+                                                               pair1_matches, pair1_rec_matches_idx)
+    return trans, mask
+
+
+def _hot_path_config() -> HotPathConfig:
+    return HotPathConfig(K=K, M1=M1, M2=M2, norm=MATCHES_NORM, rec_err=float(REC_ERR), supp_err=float(SUPP_ERR))
+
+
+def _source_arrays(frames):
+    if DETECTIONS is None:
+        raise RuntimeError("no detection source: call slam_amd.utills.set_detection_source(...) first")
+    if hasattr(DETECTIONS, "arrays"):
+        return DETECTIONS.arrays(frames)
+    per = [DETECTIONS.get(int(f)) for f in frames]
+    n_max = (max(max(len(p[0]), len(p[2])) for p in per) + 63) // 64 * 64
+    desc = np.zeros((len(per), 2, n_max, 64), np.uint8)
+    xy = np.zeros((len(per), 2, n_max, 2), np.float32)
+    count = np.zeros((len(per), 2), np.int32)
+    for i, (xl, dl, xr, dr) in enumerate(per):
+        for s, (x, d) in enumerate(((xl, dl), (xr, dr))):
+            count[i, s] = len(x)
+            xy[i, s, :len(x)] = x
+            desc[i, s, :len(x), :np.shape(d)[1]] = d
+    return desc, xy, count
+
+
+def track_pairs_arrays(frames, pair_f0, pair_f1, seeds=None):
+    """Batched core of the drivers below: frames = movie indices, pair_f0/f1 = positions in `frames`.
+    Returns (ShardResult, xy float32[F,2,n_max,2], tracked key-point indices int32[P,n_max,4])."""
+    desc, xy, count = _source_arrays(frames)
+    F, _, n_max, _ = desc.shape
+    P = len(pair_f0)
+    if seeds is None:
+        seeds = np.random.randint(0, 2 ** 32, P, dtype=np.uint64)      # one draw from the global stream per pair
+    trk = pipeline.ShardTracker(F, P, n_max, _hot_path_config())
+    res = trk.run(_cuda(desc.reshape(2 * F, n_max, 64)), _cuda(xy.reshape(2 * F, n_max, 2)), _cuda(count.reshape(2 * F)),
+                  np.asarray(pair_f0, np.int32), np.asarray(pair_f1, np.int32), seeds)
+    return res, xy, res.tracked_kp.cpu().numpy()
+
+
+def _features_of(kp_lr, xy_frame):
+    """key-point index pairs int[n, 2] (left, right) of one frame -> object array of Feature."""
+    out = np.empty(len(kp_lr), dtype=object)
+    xl, xr = xy_frame[0], xy_frame[1]
+    for i, (a, b) in enumerate(kp_lr):
+        out[i] = Feature(int(a), int(b), float(xl[a, 0]), float(xr[b, 0]), float(xl[a, 1]), float(xr[b, 1]))
+    return out
+
+
+def _check_pairs(res):
+    if (res.stats[:, 5] & _lib.SLAM_PAIR_EMPTY).any():
+        raise ValueError("low >= high")          # np.random.randint(0, 0, 4) on an empty tracked set (:502)
+
+
+def find_features_in_consecutive_frames_whole_movie(first_left_ex_cam_mat=M1, movie_len=None, seeds=None):
+    """:834-873.  -> (consecutive_frame_features, inliers_percentage, global_trans, relative_trans): the four
+    constructor arguments of DataBase (DataBase.py:39)."""
+    n = movie_len if movie_len is not None else min(MOVIE_LEN, len(DETECTIONS)) if hasattr(DETECTIONS, "__len__") else MOVIE_LEN
+    frames = np.arange(n)
+    f0, f1 = pipeline.consecutive_pairs(n)
+    res, xy, kp = track_pairs_arrays(frames, f0, f1, seeds)
+    _check_pairs(res)
+    feats, percs, rel = [], [], [first_left_ex_cam_mat]
+    for p in range(n - 1):
+        T = int(res.stats[p, 0])
+        sup = kp[p, :T][res.mask[p, :T]]
+        feats.append([_features_of(sup[:, :2], xy[p]), _features_of(sup[:, 2:], xy[p + 1])])
+        percs.append(100 * int(res.stats[p, 1]) / T)
+        rel.append(res.pose[p] if res.ok[p] else None)
+    return feats, percs, convert_trans_from_rel_to_global(rel), rel
+
+
+def whole_movie(first_left_ex_mat=M1, movie_len=None, seeds=None):
+    """:399-420.  Relative poses only."""
+    return find_features_in_consecutive_frames_whole_movie(first_left_ex_mat, movie_len, seeds)[3]
+
+
+# == Ex7: loop-closure candidate validation ==
+def create_little_tracks(first_frame_features_obj, second_frame_features_obj, first_frame_id, second_frame_id):
+    """:1149-1167."""
+    tracks = []
+    for i in range(len(first_frame_features_obj)):
+        t = Track(i)
+        t.add_feature(first_frame_id, first_frame_features_obj[i])
+        t.add_feature(second_frame_id, second_frame_features_obj[i])
+        tracks.append(t)
+    return tracks
+
+
+def apply_full_consensus_match(first_frame, second_frame):
+    """:1103-1115."""
+    a, b = read_and_rec_match(first_frame), read_and_rec_match(second_frame)
+    trans, f0, f1, perc, mask = find_features_in_consecutive_frames(*a, *b)
+    return trans, f0, f1, mask, perc
+
+
+def find_loop_cand_by_consensus(mahalanobis_dist_cand_movie_ind, mahalanobis_dist_cand_pg_ind, cur_frame_movie_ind,
+                                threshold, seeds=None):
+    """:1118-1146.  All candidates of the current frame go through the device in one pass (each frame's detections
+    and stereo match are used once instead of being recomputed per candidate, :1126)."""
+    cands = [int(c) for c in mahalanobis_dist_cand_movie_ind]
+    if not cands:
+        return []
+    frames = np.array([int(cur_frame_movie_ind)] + cands)
+    pair_f0 = np.arange(1, len(frames), dtype=np.int32)            # candidate = "frame 0" of the pair (:1128-1134)
+    pair_f1 = np.zeros(len(cands), np.int32)                       # current frame = "frame 1"
+    res, xy, kp = track_pairs_arrays(frames, pair_f0, pair_f1, seeds)
+    _check_pairs(res)
+    passed = []
+    for c in range(len(cands)):
+        T = int(res.stats[c, 0])
+        perc = 100 * int(res.stats[c, 1]) / T
+        if perc > threshold:                                       # strict (:1141)
+            sup = kp[c, :T][res.mask[c, :T]]
+            f0, f1 = _features_of(sup[:, :2], xy[1 + c]), _features_of(sup[:, 2:], xy[0])
+            passed.append([mahalanobis_dist_cand_pg_ind[c], create_little_tracks(f0, f1, cands[c], cur_frame_movie_ind)])
+    return passed

@@ -1,0 +1,123 @@
+"""The reference-shaped entry points (slam_amd.utills) against the reference's golden outputs and the oracle.
+These read like the reference's own call sites: same names, positional arguments and return types."""
+import numpy as np
+import pytest
+
+import slam_oracle as orc
+from slam_amd import types
+from slam_amd import utills as U
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-5                                                    # north_star: poses / points within 1e-5 relative
+
+
+@pytest.fixture()
+def movie(golden):
+    src = U.ArrayDetections(golden["movie_desc"], golden["movie_xy"], golden["movie_count"])
+    U.set_detection_source(src)
+    yield src
+    U.set_detection_source(None)
+
+
+def _triples(ms):
+    return np.array([[m.queryIdx, m.trainIdx, m.distance] for m in ms], np.int64).reshape(-1, 3)
+
+
+def test_match_and_rect_rejection_equal_reference(golden, movie):
+    l_kpts, l_dsc, r_kpts, matches, rec = U.read_and_rec_match(2)
+    assert isinstance(matches, np.ndarray) and matches.dtype == object
+    assert np.array_equal(_triples(matches), golden["pair_m0"])
+    assert rec == list(golden["pair_rec0"])
+    l1_kpts, l1_dsc, *_ = U.read_and_rec_match(3)
+    assert np.array_equal(_triples(U.match(l_dsc, l1_dsc)), golden["pair_tm"])
+    # sorted variant and the kNN + ratio path
+    srt = U.bf_matching(U.MATCHES_NORM, l_dsc, l1_dsc)
+    assert [m.distance for m in srt] == sorted(m.distance for m in srt)
+    q, t, d = orc.knn_ratio_match(l_dsc, l1_dsc)
+    got = U.match(l_dsc, l1_dsc, U.REGULAR_KNN)
+    assert np.array_equal(_triples(got), np.stack([q, t, d], 1))
+
+
+def test_triangulate_equals_reference(golden):
+    X = U.triangulate(U.K @ U.M1, U.K @ U.M2, golden["tri_xl"], golden["tri_xr"])
+    err = np.linalg.norm(X - golden["tri_X"], axis=1) / np.linalg.norm(golden["tri_X"], axis=1)
+    assert err.max() <= REL_TOL
+
+
+def test_consensus_match_equals_reference(golden):
+    g = golden
+    m = U.consensus_match(U.K, g["cons_T"], U.M2, g["cons_X"], g["cons_l1"], g["cons_r1"], 2)
+    assert m.dtype == bool and np.array_equal(m, g["cons_mask"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_online_est_pnp_ransac_equals_reference(golden, tag):
+    g = golden
+    X, l, r = g[f"ransac_{tag}_X"], g[f"ransac_{tag}_l1"], g[f"ransac_{tag}_r1"]
+    np.random.seed(int(g[f"ransac_{tag}_seed"]))
+    T, mask = U.online_est_pnp_ransac(4, X, U.M1, l, U.M2, r, l, U.M2, r, U.K, acc=2)
+    assert np.array_equal(mask, g[f"ransac_{tag}_mask"])                      # supporters bit-exact
+    want = g[f"ransac_{tag}_T"]
+    assert np.linalg.norm(T - want) / np.linalg.norm(want) <= REL_TOL
+    assert np.random.randint(0, 1 << 30) == int(g[f"ransac_{tag}_next_rand"])    # global stream left where the reference leaves it
+
+
+def test_online_est_pnp_ransac_empty_raises_value_error():
+    with pytest.raises(ValueError):
+        U.online_est_pnp_ransac(4, np.zeros((0, 3)), U.M1, np.zeros((0, 2)), U.M2, np.zeros((0, 2)), np.zeros((0, 2)), U.M2,
+                                np.zeros((0, 2)), U.K, acc=2)
+
+
+def test_find_features_in_consecutive_frames_equals_reference(golden, movie):
+    g = golden
+    a, b = U.read_and_rec_match(2), U.read_and_rec_match(3)
+    np.random.seed(4242)
+    trans, f0, f1, perc, mask = U.find_features_in_consecutive_frames(*a, *b)
+    assert np.array_equal(mask, g["pair_mask"]) and perc == float(g["pair_perc"])
+    assert np.array_equal([[f.get_left_kpt(), f.get_right_kpt()] for f in f0], g["pair_f0_kp"])
+    assert np.array_equal([[f.get_left_kpt(), f.get_right_kpt()] for f in f1], g["pair_f1_kp"])
+    assert np.array_equal([[*f.get_left_coor(), *f.get_right_coor()] for f in f0], g["pair_f0_xy"])
+    assert np.linalg.norm(trans - g["pair_T"]) / np.linalg.norm(g["pair_T"]) <= REL_TOL
+    t2, m2 = U.compute_trans_between_cur_to_next(*a, *b)
+    assert m2.shape == mask.shape and t2.shape == (3, 4)
+
+
+def test_whole_movie_and_database(golden, movie):
+    g = golden
+    F = len(g["movie_count"])
+    seeds = 5000 + np.arange(F - 1)
+    feats, percs, glob, rel = U.find_features_in_consecutive_frames_whole_movie(U.M1, seeds=seeds)
+    assert len(feats) == F - 1 and len(rel) == F and len(glob) == F and np.array_equal(rel[0], U.M1)
+
+    def frame(i):
+        n0, n1 = g["movie_count"][i]
+        return dict(dsc_l=g["movie_desc"][i, 0, :n0, :61], dsc_r=g["movie_desc"][i, 1, :n1, :61],
+                    xy_l=g["movie_xy"][i, 0, :n0], xy_r=g["movie_xy"][i, 1, :n1])
+
+    want_rel = [orc.M1]
+    for p in range(F - 1):
+        np.random.seed(int(seeds[p]))
+        w = orc.track_pair(frame(p), frame(p + 1))
+        sup = w["kp"][w["mask"]]
+        assert np.array_equal([[f.get_left_kpt(), f.get_right_kpt()] for f in feats[p][0]], sup[:, :2])
+        assert np.array_equal([[f.get_left_kpt(), f.get_right_kpt()] for f in feats[p][1]], sup[:, 2:])
+        assert percs[p] == w["inliers_perc"]
+        assert np.linalg.norm(rel[p + 1] - w["T"]) / np.linalg.norm(w["T"]) <= REL_TOL
+        want_rel.append(w["T"])
+    # trajectory: camera centres of the composed poses within 0.1 % of the oracle's (north_star ATE bound)
+    c_got = U.left_cameras_trajectory(glob)
+    c_want = orc.camera_centres(orc.rel_to_global(want_rel))
+    ate = np.sqrt(np.mean(np.sum((c_got - c_want) ** 2, axis=1)))
+    assert ate <= 1e-3 * np.linalg.norm(c_want[-1])
+    db = types.DataBase(feats, percs, glob, rel)
+    assert db.get_num_frames() == F and db.get_num_tracks() > 100
+    assert max(t.get_track_len() for t in db.get_tracks()) >= 3
+
+
+def test_find_loop_cand_by_consensus(golden, movie):
+    out = U.find_loop_cand_by_consensus([3, 4], [30, 40], 5, threshold=50, seeds=np.array([1, 2]))
+    assert [o[0] for o in out] == [30, 40]
+    tracks = out[1][1]
+    assert tracks[0].get_track_len() == 2 and list(tracks[0].get_frames_ids()) == [4, 5]
+    none = U.find_loop_cand_by_consensus([3, 4], [30, 40], 5, threshold=100, seeds=np.array([1, 2]))
+    assert none == []                                              # strict '>' (:1141)
