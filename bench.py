@@ -81,18 +81,12 @@ def main():
     cfg = HotPathConfig()
     trk = pipeline.ShardTracker(F, P, n_max, cfg)
 
-    gathered_pose = torch.empty((world, P, 12), dtype=torch.float64, device="cuda") if world > 1 else None
-    gathered_stat = torch.empty((world, P, 8), dtype=torch.int32, device="cuda") if world > 1 else None
+    from slam_amd import dist as sdist
 
     def step():
         res = trk.run(d_desc, d_xy, d_count, f0, f1, seeds, unpack_mask=False)
-        if world > 1:
-            # the one exchange of the path: relative poses + counters to every rank (RCCL over xGMI)
-            dist.all_gather_into_tensor(gathered_pose, trk.h_pose[:P].cuda(non_blocking=True))
-            dist.all_gather_into_tensor(gathered_stat, trk.h_stats[:P].cuda(non_blocking=True))
-            rel_all = gathered_pose.cpu().numpy().reshape(world * P, 3, 4)
-        else:
-            rel_all = res.pose
+        # the one exchange of the path: relative poses + counters to every rank (RCCL all-gather over xGMI)
+        rel_all, _ = sdist.gather_shard_results(res.pose, res.stats, world * P)
         glob = None
         if rank == 0:
             # host-side composition (utils/utills.py:749-757); pairs with no pose keep the previous camera

@@ -166,6 +166,13 @@ int slam_refit_pnp(const double *h_K, const double *d_X, const void *d_xy1, int 
                    uint8_t *d_status, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Trajectory composition (host).  Replaces convert_trans_from_rel_to_global (utils/utills.py:749-757):
+ * global[i] = rel[i] @ [global[i-1]; 0 0 0 1], started from rel[0] (so rel[0] is applied twice, as in the
+ * reference, which is harmless for [I|0]).  h_rel, h_global: [n][12] row-major 3x4.
+ */
+int slam_compose_global(const double *h_rel, int n, double *h_global);
+
+/* ---------------------------------------------------------------------------------------------
  * Whole shard.  Replaces the body of find_features_in_consecutive_frames_whole_movie
  * (utils/utills.py:834-873) / find_loop_cand_by_consensus (:1118-1146) minus detection: stereo match
  * of every frame, then per frame pair temporal match, join, triangulation, adaptive PnP-RANSAC

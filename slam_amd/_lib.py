@@ -67,6 +67,7 @@ SIGNATURES = {
                                          c_void_p, c_void_p]),
     "slam_refit_pnp": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p]),
+    "slam_compose_global": (c_int, [c_void_p, c_int, c_void_p]),
     "slam_track_device_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_void_p]),
     "slam_track_host_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_void_p]),
     "slam_track_pairs": (c_int, [c_void_p, c_void_p, c_void_p]),

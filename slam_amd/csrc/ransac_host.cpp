@@ -133,3 +133,26 @@ void RansacReplay::consume(const RansacParams &p, int n_points, const uint8_t *s
         outliers_perc = perc < 0.99 ? perc : 0.99;
     }
 }
+
+// ---- convert_trans_from_rel_to_global (utils/utills.py:749-757): running composition T_i @ [T_{i-1..0}; 0 0 0 1] ----
+// numpy evaluates `second @ hom(first)` through BLAS dgemm: k ascending, fused multiply-adds from a zero accumulator.
+extern "C" int slam_compose_global(const double *h_rel, int n, double *h_global) {
+    if (n < 0 || (n && (!h_rel || !h_global))) {
+        slam_set_error("slam_compose_global: bad arguments");
+        return SLAM_E_INVALID;
+    }
+    double last[12];
+    for (int k = 0; k < 12; ++k) last[k] = n ? h_rel[k] : 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double *T = h_rel + (size_t)i * 12;
+        double out[12];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) {
+                const double hom3 = c == 3 ? 1.0 : 0.0;
+                out[r * 4 + c] = std::fma(T[r * 4 + 3], hom3,
+                                          std::fma(T[r * 4 + 2], last[8 + c], std::fma(T[r * 4 + 1], last[4 + c], T[r * 4] * last[c])));
+            }
+        for (int k = 0; k < 12; ++k) h_global[(size_t)i * 12 + k] = last[k] = out[k];
+    }
+    return SLAM_OK;
+}

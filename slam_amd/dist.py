@@ -1,0 +1,75 @@
+"""Frame-range sharding across the GPUs of one node (one process per GPU, torch.distributed; backend "nccl" is RCCL
+on ROCm, "gloo" in the CPU tests).
+
+Consecutive-frame relative poses are independent given the detections (README.md:58 of the reference remarks the
+loop "can be done in parallel"; the loop itself is utils/utills.py:850), so rank r owns a contiguous block of frame
+pairs and the frames they touch (one halo frame, whose stereo match is recomputed rather than communicated).  There
+is no data-path collective; the only exchange is one all-gather of the per-pair results (3x4 relative poses and the
+per-pair counters, ~130 B per pair) before rank 0 composes the global trajectory on the host
+(convert_trans_from_rel_to_global, utils/utills.py:749-757)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def block_range(n_units: int, rank: int, world: int):
+    """Contiguous block partition: rank r owns [r*ceil(n/world), min(n, (r+1)*ceil(n/world)))."""
+    per = -(-n_units // world)
+    a = min(n_units, rank * per)
+    return a, min(n_units, a + per)
+
+
+def shard_frames(n_frames: int, rank: int, world: int):
+    """Pairs [a, b) of a movie with n_frames frames and the frames [a, b] they need.
+    Returns (pair_start, pair_stop, frame_start, frame_stop_exclusive)."""
+    a, b = block_range(n_frames - 1, rank, world)
+    return a, b, a, (b + 1 if b > a else a)
+
+
+def shard_list(n_units: int, rank: int, world: int):
+    """Block partition of a flat work list (loop-closure candidate pairs)."""
+    return block_range(n_units, rank, world)
+
+
+def all_gather_rows(local: torch.Tensor, n_total: int, world: int, rank: int) -> torch.Tensor:
+    """Gathers row blocks laid out by `block_range` into one [n_total, ...] tensor on every rank."""
+    if world == 1:
+        return local
+    per = -(-n_total // world)
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad.contiguous())
+    return out[:n_total]
+
+
+def gather_shard_results(pose_local: np.ndarray, stats_local: np.ndarray, n_pairs_total: int, device=None):
+    """pose_local float64[p, 3, 4], stats_local int32[p, 8] of this rank's pair block -> the full arrays on every rank."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        return pose_local, stats_local
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
+                                             if dist.get_backend() == "nccl" else torch.device("cpu"))
+    pose = all_gather_rows(torch.from_numpy(np.ascontiguousarray(pose_local)).reshape(-1, 12).to(dev), n_pairs_total, world, rank)
+    stats = all_gather_rows(torch.from_numpy(np.ascontiguousarray(stats_local)).to(dev), n_pairs_total, world, rank)
+    return pose.cpu().numpy().reshape(-1, 3, 4), stats.cpu().numpy()
+
+
+def run_sharded(n_frames: int, run_shard, first_pose=None):
+    """Runs `run_shard(frame_start, frame_stop, pair_offset) -> (pose[p,3,4], stats[p,8])` on this rank's frame range,
+    gathers, and returns (relative poses [n_frames,3,4] incl. the first camera, global poses, stats) on every rank."""
+    from .pipeline import compose_global
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    a, b, fa, fb = shard_frames(n_frames, rank, world)
+    if b > a:
+        pose, stats = run_shard(fa, fb, a)
+    else:
+        pose, stats = np.zeros((0, 3, 4)), np.zeros((0, 8), np.int32)
+    pose, stats = gather_shard_results(pose, stats, n_frames - 1)
+    first = np.eye(3, 4) if first_pose is None else np.asarray(first_pose, dtype=np.float64)
+    rel = np.concatenate([first[None], pose])
+    return rel, compose_global(rel), stats

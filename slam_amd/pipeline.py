@@ -108,15 +108,12 @@ def consecutive_pairs(n_frames: int):
     return f0, f0 + 1
 
 
-def compose_global(rel: np.ndarray, first=None) -> np.ndarray:
+def compose_global(rel: np.ndarray) -> np.ndarray:
     """convert_trans_from_rel_to_global (utils/utills.py:749-757): running left-composition
     T_i @ [T_{i-1..}; 0 0 0 1].  rel float64[n, 3, 4] (rel[0] = the first camera, [I|0])."""
+    rel = np.ascontiguousarray(rel, dtype=np.float64)
     out = np.empty_like(rel)
-    last = rel[0] if first is None else first
-    for i in range(len(rel)):
-        hom = np.vstack([last, [0.0, 0.0, 0.0, 1.0]])
-        last = rel[i] @ hom
-        out[i] = last
+    _lib.check(_lib.lib().slam_compose_global(rel.ctypes.data, len(rel), out.ctypes.data))
     return out
 
 
