@@ -28,8 +28,12 @@ sys.path.insert(0, ROOT)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBPS = 8000.0
 # VALU instructions the matcher executes per descriptor pair (NORM_HAMMING2, 64-byte rows): 8 x (v_xor, v_bitop3,
-# v_bcnt) + v_lshl_or + v_min + v_med3; SURVEY section 8(d) counts the naive formulation at 80 (+4) per pair.
-EXEC_OPS_PER_PAIR = 27
+# v_bcnt) + v_cmp (the key/min update behind it runs for a few percent of the rows); SURVEY section 8(d) counts the
+# naive formulation at 80 (+4) per pair.  v_bcnt issues at half rate on gfx950 (tools/valu_peak.hip), so a pair
+# costs 8 x (1 + 1 + 2) + 1 = 33 full-rate issue slots.
+EXEC_OPS_PER_PAIR = 25
+ISSUE_SLOTS_PER_PAIR = 33
+VALU_SUSTAINED_TSLOTS = 62.0      # measured: v_xor / v_bitop3 / v_add sustained, profiles/r1_valu_peak_microbench.txt
 SURVEY_OPS_PER_PAIR = 80
 
 
@@ -43,6 +47,7 @@ def parse():
     ap.add_argument("--cpu-pairs", type=int, default=24, help="frame pairs timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--chunks", type=int, default=2, help="frame-range chunks pipelined over two HIP streams per GPU")
     return ap.parse_args()
 
 
@@ -79,7 +84,7 @@ def main():
     P = len(f0)
     seeds = 1000 + rank * P + np.arange(P)            # np.random.seed(1000 + pair index)
     cfg = HotPathConfig()
-    trk = pipeline.ShardTracker(F, P, n_max, cfg)
+    trk = pipeline.ShardTracker(F, P, n_max, cfg, n_chunks=args.chunks)
 
     from slam_amd import dist as sdist
 
@@ -128,11 +133,15 @@ def main():
         alg_bytes = int(cnt.sum()) * 64 * 1 + (2 * F - 1) * n_max * 4  # every descriptor row once + the key arrays
         stages = np.mean(np.array(stage_ms), axis=0)
         roofline = {
-            "kernel": "allpairs_top2_kernel (2 launches per step: stereo + temporal)",
+            "kernel": "allpairs_top2_kernel (stereo + temporal problems, one launch per chunk)",
             "bound": "valu", "unit": "Tlaneop/s",
             "achieved": round(exec_rate, 3), "peak": round(VALU_PEAK_TLANEOPS, 2),
             "frac": round(exec_rate / VALU_PEAK_TLANEOPS, 4),
             "ops_per_descriptor_pair_executed": EXEC_OPS_PER_PAIR,
+            "issue_slots_per_descriptor_pair": ISSUE_SLOTS_PER_PAIR,
+            "issue_slot_rate_Tslots": round(desc_pairs * ISSUE_SLOTS_PER_PAIR / (m_ms * 1e-3) / 1e12, 3),
+            "issue_slot_frac_of_nominal_peak": round(desc_pairs * ISSUE_SLOTS_PER_PAIR / (m_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 4),
+            "issue_slot_frac_of_measured_sustained": round(desc_pairs * ISSUE_SLOTS_PER_PAIR / (m_ms * 1e-3) / 1e12 / VALU_SUSTAINED_TSLOTS, 4),
             "achieved_survey_units": round(desc_pairs * SURVEY_OPS_PER_PAIR / (m_ms * 1e-3) / 1e12, 3),
             "descriptor_pairs_per_step": desc_pairs, "kernel_ms_per_step": round(m_ms, 4),
             "hbm_algorithmic_GBps": round(alg_bytes / (m_ms * 1e-3) / 1e9, 2), "hbm_peak_GBps": HBM_PEAK_GBPS,

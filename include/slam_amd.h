@@ -177,7 +177,7 @@ int slam_compose_global(const double *h_rel, int n, double *h_global);
  * (utils/utills.py:834-873) / find_loop_cand_by_consensus (:1118-1146) minus detection: stereo match
  * of every frame, then per frame pair temporal match, join, triangulation, adaptive PnP-RANSAC
  * (online_est_pnp_ransac, :474-530, replayed on the host over batched device results) and refit.
- * Synchronous: returns when the host outputs are filled.
+ * Synchronous: returns when the host outputs are filled.  slam_track_last_timing[7] = number of match launches.
  */
 typedef struct SlamTrackConfig {
     double K[9];             /* calibration, row-major */
@@ -191,6 +191,10 @@ typedef struct SlamTrackConfig {
     int32_t max_draws;       /* bound on draws incl. failed ones (the reference is unbounded); 0 = 64 * max_iterations */
     int32_t norm;            /* SLAM_NORM_HAMMING2 */
     int32_t first_chunk;     /* hypotheses evaluated speculatively in round 1 (0 = 64) */
+    int32_t pipeline_chunks; /* > 1: split the pair list into this many contiguous blocks and pipeline them over two
+                                internal streams (RANSAC rounds of one block overlap the matching of the next);
+                                needs pairs that are local in time, otherwise the call falls back to one block */
+    int32_t reserved;
 } SlamTrackConfig;
 
 typedef struct SlamTrackIO {
@@ -225,7 +229,7 @@ size_t slam_track_host_workspace_bytes(int n_frames, int n_pairs, int n_max, con
 int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *io, void *stream);
 
 /* per-stage device times (ms) of the last slam_track_pairs call on this thread, measured with HIP events on
- * `stream`: [0] match, [1] join, [2] triangulate, [3] hypotheses+score (all rounds), [4] mask+refit,
+ * `stream`: [0] match (time with a match launch in flight), [1] join, [2] triangulate, [3] hypotheses+score (all rounds), [4] mask+refit,
  * [5] whole call wall (host clock), [6] host replay + RNG (host clock), [7] match kernel launches */
 int slam_track_last_timing(double *h_ms8);
 

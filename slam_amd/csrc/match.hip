@@ -6,14 +6,17 @@
 // Shape of the work: integer VALU (xor / or / popcount), not a GEMM and not HBM bound
 // (2000 x 2000 rows x 64 B = 256 KB in, 35 lane-ops per row pair).  Mapping:
 //   - every lane owns ROWS "A" rows in registers (64 VGPRs), pre-transformed so that a
-//     NORM_HAMMING2 distance over 64 bytes costs 8 x (xor, xor, or, popcount-accumulate):
+//     NORM_HAMMING2 distance over 64 bytes costs 8 x (v_xor, v_bitop3 "(a^b)|c", v_bcnt accumulate):
 //     each dword pair (w0, w1) is re-packed into E = even bits of w0 | even bits of w1 << 1 and
 //     O = odd bits of w0 >> 1 | odd bits of w1, so a 2-bit cell differs iff (Ea^Eb)|(Oa^Ob) has
 //     its bit set (16 + 16 cells per dword pair, one popcount each).
 //   - "B" rows are staged through LDS in tiles (double buffered, transformed on the way in) and
 //     read back with ds_read_b128 broadcasts: one LDS read feeds ROWS x 64 distance updates.
-//   - running top-2 per A row as packed keys (distance << 20 | B row): one v_min_u32 and one
-//     v_med3_u32 per pair; lowest index wins ties because the index is in the key's low bits.
+//   - running best (cross-check) or top-2 (kNN) per A row as packed keys (distance << 20 | B row); lowest index
+//     wins ties because the index is in the key's low bits.  The key/min/med3 updates are half-rate instructions
+//     on gfx950 (tools/valu_peak.hip), so they sit behind a wave-uniform "does any lane improve" test and are
+//     skipped for most B rows.
+//   - tile shape (4 rows/lane, 256 threads, 128-row B tiles) chosen by a sweep on the MI355X.
 //   - cross-check (OpenCV batchDistance(crosscheck=true)): A = train rows; the nearest query of
 //     every train row is scattered with atomicMin on key (distance << 20 | train row) into the
 //     query's slot.  min is order independent, so the result is deterministic.
@@ -21,10 +24,21 @@
 
 namespace {
 
-constexpr int ROWS = 4;            // A rows per lane
-constexpr int BLOCK = 128;         // threads per workgroup (2 waves)
+#ifndef SLAM_ROWS
+#define SLAM_ROWS 4
+#endif
+#ifndef SLAM_BLOCK
+#define SLAM_BLOCK 256
+#endif
+#ifndef SLAM_TILE_B
+#define SLAM_TILE_B 128
+#endif
+constexpr int ROWS = SLAM_ROWS;    // A rows per lane
+constexpr int BLOCK = SLAM_BLOCK;  // threads per workgroup
 constexpr int TILE_A = ROWS * BLOCK;
-constexpr int TILE_B = 128;        // B rows per LDS tile (8 KB)
+constexpr int TILE_B = SLAM_TILE_B;   // B rows per LDS tile (64 B each)
+constexpr int STAGE = TILE_B * 4 / BLOCK;   // uint4 moved per thread per tile
+static_assert(STAGE * BLOCK == TILE_B * 4 && STAGE >= 1, "tile must divide evenly over the workgroup");
 constexpr unsigned NONE = SLAM_KEY_NONE;
 
 struct MatchBatch {
@@ -86,7 +100,8 @@ __device__ __forceinline__ void top2_insert(unsigned &m1, unsigned &m2, unsigned
 }
 
 // FUSED: cross-check scatter straight from the all-pairs kernel (nsplit == 1).
-template <bool NORM2, bool FUSED>
+// TOP2: keep the second best too (kNN mode); cross-check needs only the nearest row.
+template <bool NORM2, bool FUSED, bool TOP2>
 __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
     __shared__ uint4 tile[2][TILE_B * 4];
 
@@ -138,21 +153,24 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
     unsigned m1[ROWS], m2[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) m1[r] = m2[r] = NONE;
+    unsigned gate[ROWS];          // distance a new row must beat: that of the worst entry kept
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) gate[r] = NONE >> SLAM_KEY_SHIFT;
 
-    // prologue: first tile -> LDS.  A tile is TILE_B*4 = 512 uint4; each thread moves 4 of them, coalesced.
-    uint4 stage[4];
+    // prologue: first tile -> LDS.  A tile is TILE_B*4 uint4; each thread moves STAGE of them, coalesced.
+    uint4 stage[STAGE];
     auto load_tile = [&](int tb) {
         const size_t base = (size_t)tb * TILE_B * 4;
         const size_t lim = (size_t)nb * 4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < STAGE; ++k) {
             const size_t idx = base + k * BLOCK + tid;
             stage[k] = idx < lim ? B[idx] : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) tile[buf][k * BLOCK + tid] = pack_cells<NORM2>(stage[k]);
+        for (int k = 0; k < STAGE; ++k) tile[buf][k * BLOCK + tid] = pack_cells<NORM2>(stage[k]);
     };
 
     if (tb0 < tb1) {
@@ -172,14 +190,33 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
         for (int j = 0; j < rows_here; ++j) {
             const uint4 b0 = t[j * 4 + 0], b1 = t[j * 4 + 1], b2 = t[j * 4 + 2], b3 = t[j * 4 + 3];
             const unsigned jg = (unsigned)(jbase + j);
+            unsigned d[ROWS];
+            bool improves = false;
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
-                unsigned d = 0;
-                d = dist_quad<NORM2>(a[r][0], b0, d);
-                d = dist_quad<NORM2>(a[r][1], b1, d);
-                d = dist_quad<NORM2>(a[r][2], b2, d);
-                d = dist_quad<NORM2>(a[r][3], b3, d);
-                top2_insert(m1[r], m2[r], (d << SLAM_KEY_SHIFT) | jg);
+                unsigned acc = 0;
+                acc = dist_quad<NORM2>(a[r][0], b0, acc);
+                acc = dist_quad<NORM2>(a[r][1], b1, acc);
+                acc = dist_quad<NORM2>(a[r][2], b2, acc);
+                acc = dist_quad<NORM2>(a[r][3], b3, acc);
+                d[r] = acc;
+                improves |= acc < gate[r];
+            }
+            // B rows are scanned in ascending order, so a row enters a lane's list iff its distance is strictly
+            // below the list's worst distance.  The key / min / med3 updates (half-rate instructions) are skipped
+            // for the whole wave when no lane improves, which is the common case after the first few hundred rows.
+            if (__any(improves)) {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const unsigned key = (d[r] << SLAM_KEY_SHIFT) | jg;
+                    if (TOP2) {
+                        top2_insert(m1[r], m2[r], key);
+                        gate[r] = m2[r] >> SLAM_KEY_SHIFT;
+                    } else {
+                        m1[r] = min(m1[r], key);
+                        gate[r] = m1[r] >> SLAM_KEY_SHIFT;
+                    }
+                }
             }
         }
         if (more) store_tile(buf ^ 1);
@@ -238,10 +275,18 @@ template <bool FUSED>
 void launch_allpairs(const MatchBatch &mb, int norm, hipStream_t st) {
     const unsigned total = (unsigned)mb.tiles_per_prob * (unsigned)mb.n_prob;
     dim3 grid((total + 7u) / 8u * 8u, mb.nsplit);
-    if (norm == SLAM_NORM_HAMMING2)
-        hipLaunchKernelGGL((allpairs_top2_kernel<true, FUSED>), grid, dim3(BLOCK), 0, st, mb);
-    else
-        hipLaunchKernelGGL((allpairs_top2_kernel<false, FUSED>), grid, dim3(BLOCK), 0, st, mb);
+    const bool top2 = mb.out2 != nullptr;
+    if (norm == SLAM_NORM_HAMMING2) {
+        if (top2)
+            hipLaunchKernelGGL((allpairs_top2_kernel<true, false, true>), grid, dim3(BLOCK), 0, st, mb);
+        else
+            hipLaunchKernelGGL((allpairs_top2_kernel<true, FUSED, false>), grid, dim3(BLOCK), 0, st, mb);
+    } else {
+        if (top2)
+            hipLaunchKernelGGL((allpairs_top2_kernel<false, false, true>), grid, dim3(BLOCK), 0, st, mb);
+        else
+            hipLaunchKernelGGL((allpairs_top2_kernel<false, FUSED, false>), grid, dim3(BLOCK), 0, st, mb);
+    }
 }
 
 int pick_nsplit(int na, int nb) {

@@ -10,6 +10,7 @@
 //      than were evaluated speculatively go to the next, larger round
 //   5. supporter mask of the winning hypothesis + LM refit.
 // Host <-> device synchronisation: one per RANSAC round (normally one) and one at the end.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -61,6 +62,8 @@ struct Buffers {
         *h_cntR, *h_best_idxR;
     uint8_t *h_status0, *h_statusR, *h_refit_status;
     int D0, W0, RB;
+    // temporal keys of a chunk with F frames start right after its F stereo key rows
+    uint32_t *temporal_key_at(int F, int N) const { return stereo_key + (size_t)F * N; }
 };
 
 int first_chunk(const SlamTrackConfig *cfg) { return cfg && cfg->first_chunk > 0 ? cfg->first_chunk : 64; }
@@ -71,8 +74,8 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     b.W0 = b.D0 * WORDS_PER_DRAW;
     b.RB = (int)(HYP_BUDGET / ((long)b.D0 * 8));
     if (b.RB < 1) b.RB = 1;
-    b.stereo_key = d.take<uint32_t>(Fs * N);
-    b.temporal_key = d.take<uint32_t>(Ps * N);
+    b.stereo_key = d.take<uint32_t>((Fs + Ps) * N);   // one key array: F stereo problems, then P temporal ones
+    b.temporal_key = b.stereo_key ? b.stereo_key + Fs * N : nullptr;
     b.prob_q = d.take<int32_t>(Fs + Ps);
     b.prob_t = d.take<int32_t>(Fs + Ps);
     b.pair_f0 = d.take<int32_t>(Ps);
@@ -154,27 +157,326 @@ void parallel_for(int n, int grain, F fn) {
 }
 
 thread_local double g_timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-thread_local hipEvent_t g_ev[8];
-thread_local bool g_ev_ready = false;
 
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+struct Shared {
+    const SlamTrackConfig *cfg;
+    const SlamTrackIO *io;
+    Mat33 K;
+    Mat34 M2, Pm, Qm;
+    RansacParams rp;
+    double thr;
+    int norm, N;
+};
+
+// One workspace + one stream: a chunk of the shard goes through front() -> mid() -> back().
+struct Lane {
+    Buffers b;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[6];
+    bool ev_ready = false;
+    // the chunk in flight
+    int F = 0, P = 0, pair0 = 0;
+    const uint8_t *d_desc = nullptr;
+    const float *d_xy = nullptr;
+    const int32_t *d_count = nullptr;
+    std::vector<int32_t> f0, f1;
+    const uint32_t *seed = nullptr;
+    std::vector<RansacReplay> rs;
+    std::vector<int> active;
+    double host_ms = 0, stage_ms[5] = {0, 0, 0, 0, 0};
+    hipEvent_t base = nullptr;                       // common time origin of the call (caller's stream)
+    std::vector<std::pair<float, float>> match_iv;   // [start, end] of every match launch, ms since `base`
+
+    int ensure_events() {
+        if (!ev_ready) {
+            for (auto &e : ev) SLAM_HIP_CHECK(hipEventCreate(&e));
+            ev_ready = true;
+        }
+        return SLAM_OK;
+    }
+
+    void set_chunk(const Shared &sh, int a, int e, int lo, int hi) {
+        const SlamTrackIO *io = sh.io;
+        pair0 = a;
+        P = e - a;
+        F = hi - lo;
+        d_desc = io->d_desc + (size_t)2 * lo * sh.N * 64;
+        d_xy = io->d_xy + (size_t)2 * lo * sh.N * 2;
+        d_count = io->d_count + 2 * lo;
+        f0.resize(P);
+        f1.resize(P);
+        for (int p = 0; p < P; ++p) {
+            f0[p] = io->h_pair_f0[a + p] - lo;
+            f1[p] = io->h_pair_f1[a + p] - lo;
+        }
+        seed = io->h_pair_seed + a;
+    }
+
+    // everything up to the first host decision, asynchronously: match, join, triangulate, RANSAC round 0, D2H
+    int front(const Shared &sh) {
+        const int N = sh.N, D0 = b.D0, W0 = b.W0;
+        int rc = ensure_events();
+        if (rc) return rc;
+        for (int f = 0; f < F; ++f) {
+            b.h_prob[f] = 2 * f;
+            b.h_prob[F + P + f] = 2 * f + 1;
+        }
+        for (int p = 0; p < P; ++p) {
+            b.h_prob[F + p] = 2 * f0[p];
+            b.h_prob[F + P + F + p] = 2 * f1[p];
+        }
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.prob_q, b.h_prob, sizeof(int32_t) * (F + P), hipMemcpyHostToDevice, st));
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.prob_t, b.h_prob + F + P, sizeof(int32_t) * (F + P), hipMemcpyHostToDevice, st));
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.pair_f0, f0.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.pair_f1, f1.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
+        SLAM_HIP_CHECK(hipEventRecord(ev[0], st));
+        // ---- 1. matching: F stereo + P temporal problems, ONE launch over the contiguous key array ----
+        rc = slam_match_hamming_batched(d_desc, d_count, N, b.prob_q, b.prob_t, F + P, sh.norm, SLAM_MATCH_CROSSCHECK,
+                                        b.stereo_key, nullptr, st);
+        if (rc) return rc;
+        SLAM_HIP_CHECK(hipEventRecord(ev[1], st));
+        // ---- host, while the GPU matches: raw MT19937 words of every pair's stream ----
+        const double t0 = now_ms();
+        parallel_for(P, 64, [&](int a, int e) {
+            for (int p = a; p < e; ++p) slam_mt_seed_words(seed[p], b.h_words0 + (size_t)p * W0, W0);
+        });
+        host_ms += now_ms() - t0;
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.words0, b.h_words0, sizeof(uint32_t) * (size_t)P * W0, hipMemcpyHostToDevice, st));
+        // ---- 2. join, 3. triangulate ----
+        rc = slam_launch_rect_join(d_xy, d_count, N, b.stereo_key, b.temporal_key_at(F, N), b.pair_f0, b.pair_f1, P,
+                                   sh.cfg->rec_err, b.tcount, sh.io->d_tracked_kp + (size_t)pair0 * N * 4, b.xy0, b.xy1,
+                                   b.aux, st);
+        if (rc) return rc;
+        SLAM_HIP_CHECK(hipEventRecord(ev[2], st));
+        rc = slam_launch_triangulate(sh.Pm, sh.Qm, b.xy0, b.tcount, P, N, b.X, st);
+        if (rc) return rc;
+        SLAM_HIP_CHECK(hipEventRecord(ev[3], st));
+        // ---- 4. RANSAC round 0: D0 speculative draws for every pair ----
+        rc = slam_launch_map_samples(b.words0, W0, b.tcount, nullptr, P, D0, b.sample0, b.produced0, st);
+        if (rc) return rc;
+        rc = slam_launch_p3p(sh.K, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.sample0, D0, 0, D0, b.pose0, b.status0, st);
+        if (rc) return rc;
+        rc = slam_launch_score(sh.K, sh.M2, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.pose0, b.status0, D0, sh.thr, b.cnt0,
+                               nullptr, st);
+        if (rc) return rc;
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_tcount, b.tcount, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_aux, b.aux, sizeof(int32_t) * 2 * P, hipMemcpyDeviceToHost, st));
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_produced0, b.produced0, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_status0, b.status0, (size_t)P * D0, hipMemcpyDeviceToHost, st));
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_cnt0, b.cnt0, sizeof(int32_t) * (size_t)P * D0, hipMemcpyDeviceToHost, st));
+        return SLAM_OK;
+    }
+
+    // host replay of the adaptive loop, later rounds where needed, then launch mask + refit + D2H
+    int mid(const Shared &sh) {
+        const int N = sh.N, D0 = b.D0;
+        const RansacParams &rp = sh.rp;
+        SLAM_HIP_CHECK(hipStreamSynchronize(st));
+        double t_h0 = now_ms();
+        rs.assign(P, RansacReplay());
+        active.clear();
+        for (int p = 0; p < P; ++p) {
+            RansacReplay &r = rs[p];
+            const int n = b.h_tcount[p];
+            if (n <= 0)
+                r.finished = true;
+            else
+                r.consume(rp, n, b.h_status0 + (size_t)p * D0, b.h_cnt0 + (size_t)p * D0, 0, b.h_produced0[p]);
+            b.h_best_idx[p] = r.best_draw;
+            if (!r.finished) active.push_back(p);
+        }
+        host_ms += now_ms() - t_h0;
+        SLAM_HIP_CHECK(hipMemsetAsync(b.best_status, 0, P, st));
+        SLAM_HIP_CHECK(hipMemsetAsync(b.best_pose, 0xFF, sizeof(double) * 12 * (size_t)P, st));   // NaN pattern
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.best_idx, b.h_best_idx, sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gather_best_kernel, dim3(slam_div_up((long)P * 12, 256)), dim3(256), 0, st, b.pose0, b.status0,
+                           b.best_idx, nullptr, P, D0, b.best_pose, b.best_status);
+        SLAM_HIP_CHECK(hipGetLastError());
+
+        // ---- later rounds for the pairs whose loop wanted more draws than were evaluated ----
+        // The host now knows every pair's point count, so it draws the sample indices itself (same stream, restarted
+        // from the pair's seed) and uploads only the new range [draws consumed so far, + n_eval).
+        long n_eval_l = (long)D0 * 8;
+        int rc;
+        while (!active.empty()) {
+            if (n_eval_l > HYP_BUDGET) n_eval_l = HYP_BUDGET;
+            const int n_eval = (int)n_eval_l;
+            int rows_per_batch = (int)(HYP_BUDGET / n_eval);
+            if (rows_per_batch > b.RB) rows_per_batch = b.RB;
+            std::vector<int> still;
+            for (size_t a0 = 0; a0 < active.size(); a0 += rows_per_batch) {
+                const int rows = (int)std::min<size_t>(rows_per_batch, active.size() - a0);
+                t_h0 = now_ms();
+                parallel_for(rows, 1, [&](int a, int e) {
+                    std::vector<int32_t> tmp;
+                    for (int r = a; r < e; ++r) {
+                        const int p = active[a0 + r];
+                        const long begin = rs[p].draws, total = (begin + n_eval) * 4;
+                        tmp.resize(total);
+                        slam_randint_host(seed[p], (uint32_t)b.h_tcount[p], tmp.data(), total);
+                        std::memcpy(b.h_sampleR + (size_t)r * n_eval * 4, tmp.data() + begin * 4,
+                                    sizeof(int32_t) * (size_t)n_eval * 4);
+                    }
+                });
+                for (int r = 0; r < rows; ++r) b.h_seg_of[r] = active[a0 + r];
+                host_ms += now_ms() - t_h0;
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.seg_of, b.h_seg_of, sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.sampleR, b.h_sampleR, sizeof(int32_t) * (size_t)rows * n_eval * 4,
+                                              hipMemcpyHostToDevice, st));
+                rc = slam_launch_p3p(sh.K, b.X, b.xy1, 0, b.tcount, b.seg_of, rows, N, b.sampleR, n_eval, 0, n_eval, b.poseR,
+                                     b.statusR, st);
+                if (rc) return rc;
+                rc = slam_launch_score(sh.K, sh.M2, b.X, b.xy1, 0, b.tcount, b.seg_of, rows, N, b.poseR, b.statusR, n_eval,
+                                       sh.thr, b.cntR, nullptr, st);
+                if (rc) return rc;
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.h_statusR, b.statusR, (size_t)rows * n_eval, hipMemcpyDeviceToHost, st));
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.h_cntR, b.cntR, sizeof(int32_t) * (size_t)rows * n_eval, hipMemcpyDeviceToHost, st));
+                SLAM_HIP_CHECK(hipStreamSynchronize(st));
+                t_h0 = now_ms();
+                for (int r = 0; r < rows; ++r) {
+                    const int p = active[a0 + r];
+                    RansacReplay &s = rs[p];
+                    const int before = s.best_draw, begin = s.draws;
+                    s.consume(rp, b.h_tcount[p], b.h_statusR + (size_t)r * n_eval, b.h_cntR + (size_t)r * n_eval, begin,
+                              begin + n_eval);
+                    b.h_best_idxR[r] = s.best_draw != before ? s.best_draw - begin : -1;
+                    if (!s.finished) still.push_back(p);
+                }
+                host_ms += now_ms() - t_h0;
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.best_idxR, b.h_best_idxR, sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(gather_best_kernel, dim3(slam_div_up((long)rows * 12, 256)), dim3(256), 0, st, b.poseR,
+                                   b.statusR, b.best_idxR, b.seg_of, rows, n_eval, b.best_pose, b.best_status);
+                SLAM_HIP_CHECK(hipGetLastError());
+                // the next sub-batch reuses the host staging buffers: drain before overwriting them
+                SLAM_HIP_CHECK(hipStreamSynchronize(st));
+            }
+            active.swap(still);
+            n_eval_l *= 8;
+        }
+        SLAM_HIP_CHECK(hipEventRecord(ev[4], st));
+        // ---- 5. supporter mask of the winner (pre-refit, as the reference returns) + refit ----
+        rc = slam_launch_score(sh.K, sh.M2, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.best_pose, b.best_status, 1, sh.thr,
+                               b.best_cnt, b.mask, st);
+        if (rc) return rc;
+        rc = slam_launch_refit(sh.K, b.X, b.xy1, 0, b.tcount, P, N, b.mask, b.best_pose, b.refit_pose, b.refit_status, st);
+        if (rc) return rc;
+        SLAM_HIP_CHECK(hipEventRecord(ev[5], st));
+        const SlamTrackIO *io = sh.io;
+        SLAM_HIP_CHECK(hipMemcpyAsync(io->h_pose + (size_t)pair0 * 12, b.refit_pose, sizeof(double) * 12 * (size_t)P, hipMemcpyDeviceToHost, st));
+        SLAM_HIP_CHECK(hipMemcpyAsync(io->h_mask + (size_t)pair0 * (N / 64), b.mask, sizeof(uint64_t) * (size_t)P * (N / 64), hipMemcpyDeviceToHost, st));
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_best_cnt, b.best_cnt, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_refit_status, b.refit_status, P, hipMemcpyDeviceToHost, st));
+        return SLAM_OK;
+    }
+
+    // wait for the chunk's results and write its per-pair counters
+    int back(const Shared &sh) {
+        SLAM_HIP_CHECK(hipStreamSynchronize(st));
+        const SlamTrackIO *io = sh.io;
+        for (int p = 0; p < P; ++p) {
+            const RansacReplay &r = rs[p];
+            int32_t *s = io->h_stats + (size_t)(pair0 + p) * 8;
+            const int n = b.h_tcount[p];
+            int status = 0;
+            if (n <= 0) status |= SLAM_PAIR_EMPTY;
+            if (r.hit_cap) status |= SLAM_PAIR_DRAW_CAP;
+            if (n > 0 && !b.h_refit_status[p]) status |= SLAM_PAIR_FEW;
+            if (b.h_refit_status[p]) status |= SLAM_PAIR_OK;
+            s[0] = n;
+            s[1] = n > 0 && r.best_draw >= 0 ? b.h_best_cnt[p] : 0;
+            s[2] = r.it;
+            s[3] = r.draws;
+            s[4] = r.best_draw;
+            s[5] = status;
+            s[6] = b.h_aux[2 * p];
+            s[7] = b.h_aux[2 * p + 1];
+            if (n <= 0)
+                for (int k = 0; k < 12; ++k) io->h_pose[(size_t)(pair0 + p) * 12 + k] = std::nan("");
+        }
+        float ms = 0;
+        for (int k = 0; k < 5; ++k) {
+            hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+            stage_ms[k] += ms;
+        }
+        float t0 = 0, t1 = 0;
+        hipEventElapsedTime(&t0, base, ev[0]);
+        hipEventElapsedTime(&t1, base, ev[1]);
+        match_iv.emplace_back(t0, t1);
+        return SLAM_OK;
+    }
+};
+
+// total time during which at least one match kernel was in flight (lanes overlap, so durations must not be summed)
+double union_ms(std::vector<std::pair<float, float>> iv) {
+    std::sort(iv.begin(), iv.end());
+    double total = 0, end = -1e30;
+    for (auto &p : iv) {
+        if (p.first > end) {
+            total += p.second - p.first;
+            end = p.second;
+        } else if (p.second > end) {
+            total += p.second - end;
+            end = p.second;
+        }
+    }
+    return total;
+}
+
+thread_local Lane g_lane[2];
+thread_local hipStream_t g_side_stream[2] = {nullptr, nullptr};
+thread_local hipEvent_t g_fork = nullptr;
+thread_local hipEvent_t g_base = nullptr;
+
+struct Chunk { int a, e, lo, hi; };
+
+// contiguous pair blocks; each needs the frames [lo, hi)
+std::vector<Chunk> plan_chunks(const SlamTrackIO *io, int n_chunks) {
+    std::vector<Chunk> out;
+    const int P = io->n_pairs;
+    if (n_chunks <= 1 || P < 2 * n_chunks) return out;
+    const int per = (P + n_chunks - 1) / n_chunks;
+    for (int a = 0; a < P; a += per) {
+        const int e = a + per < P ? a + per : P;
+        int lo = io->n_frames, hi = 0;
+        for (int p = a; p < e; ++p) {
+            lo = std::min(lo, std::min(io->h_pair_f0[p], io->h_pair_f1[p]));
+            hi = std::max(hi, std::max(io->h_pair_f0[p], io->h_pair_f1[p]) + 1);
+        }
+        out.push_back({a, e, lo, hi});
+    }
+    return out;
+}
+
+size_t lane_bytes(int F, int P, int N, const SlamTrackConfig *cfg, bool host) {
+    Carver d(nullptr), h(nullptr);
+    Buffers b;
+    layout(F, P, N, cfg, d, h, b);
+    return slam_align_up((host ? h.off : d.off) + 256, 4096);
+}
+
+// worst-case bytes: the whole shard in one lane, or two lanes of consecutive-frame chunks
+size_t workspace_bytes(int F, int P, int N, const SlamTrackConfig *cfg, bool host) {
+    size_t need = lane_bytes(F, P, N, cfg, host);
+    const int C = cfg ? cfg->pipeline_chunks : 0;
+    if (C > 1 && P >= 2 * C) {
+        const int per = (P + C - 1) / C;
+        need = std::max(need, 2 * lane_bytes(per + 1, per, N, cfg, host));
+    }
+    return need;
+}
+
 }  // namespace
 
 extern "C" size_t slam_track_device_workspace_bytes(int n_frames, int n_pairs, int n_max, const SlamTrackConfig *cfg) {
-    Carver d(nullptr), h(nullptr);
-    Buffers b;
-    layout(n_frames, n_pairs, n_max, cfg, d, h, b);
-    return d.off + 256;
+    return workspace_bytes(n_frames, n_pairs, n_max, cfg, false);
 }
 
 extern "C" size_t slam_track_host_workspace_bytes(int n_frames, int n_pairs, int n_max, const SlamTrackConfig *cfg) {
-    Carver d(nullptr), h(nullptr);
-    Buffers b;
-    layout(n_frames, n_pairs, n_max, cfg, d, h, b);
-    return h.off + 256;
+    return workspace_bytes(n_frames, n_pairs, n_max, cfg, true);
 }
 
 extern "C" int slam_track_last_timing(double *h_ms8) {
@@ -199,212 +501,105 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
         SLAM_REQUIRE(io->h_pair_f0[p] >= 0 && io->h_pair_f0[p] < F && io->h_pair_f1[p] >= 0 && io->h_pair_f1[p] < F,
                      "slam_track_pairs: pair %d references a frame outside [0, %d)", p, F);
 
-    Carver dc(io->d_workspace), hc(io->h_workspace);
-    Buffers b;
-    layout(F, P, N, cfg, dc, hc, b);
-    if (dc.off > io->d_workspace_bytes || hc.off > io->h_workspace_bytes) {
-        slam_set_error("slam_track_pairs: workspace too small (device %zu < %zu or host %zu < %zu)",
-                       io->d_workspace_bytes, dc.off, io->h_workspace_bytes, hc.off);
-        return SLAM_E_WORKSPACE;
-    }
-    if (!g_ev_ready) {
-        for (auto &e : g_ev) SLAM_HIP_CHECK(hipEventCreate(&e));
-        g_ev_ready = true;
-    }
-    Mat33 K;
-    Mat34 M2, Pm, Qm;
-    for (int i = 0; i < 9; ++i) K.m[i] = cfg->K[i];
-    for (int i = 0; i < 12; ++i) M2.m[i] = cfg->M2[i];
+    Shared sh;
+    sh.cfg = cfg;
+    sh.io = io;
+    sh.N = N;
+    for (int i = 0; i < 9; ++i) sh.K.m[i] = cfg->K[i];
+    for (int i = 0; i < 12; ++i) sh.M2.m[i] = cfg->M2[i];
     // K @ M1, K @ M2 (numpy/BLAS accumulation order)
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 4; ++j) {
-            Pm.m[i * 4 + j] = std::fma(cfg->K[i * 3 + 2], cfg->M1[8 + j], std::fma(cfg->K[i * 3 + 1], cfg->M1[4 + j], cfg->K[i * 3] * cfg->M1[j]));
-            Qm.m[i * 4 + j] = std::fma(cfg->K[i * 3 + 2], cfg->M2[8 + j], std::fma(cfg->K[i * 3 + 1], cfg->M2[4 + j], cfg->K[i * 3] * cfg->M2[j]));
+            sh.Pm.m[i * 4 + j] = std::fma(cfg->K[i * 3 + 2], cfg->M1[8 + j], std::fma(cfg->K[i * 3 + 1], cfg->M1[4 + j], cfg->K[i * 3] * cfg->M1[j]));
+            sh.Qm.m[i * 4 + j] = std::fma(cfg->K[i * 3 + 2], cfg->M2[8 + j], std::fma(cfg->K[i * 3 + 1], cfg->M2[4 + j], cfg->K[i * 3] * cfg->M2[j]));
         }
-    RansacParams rp;
-    rp.prob = cfg->prob;
-    rp.max_iterations = cfg->max_iterations;
-    rp.fixed_iterations = cfg->fixed_iterations;
-    rp.max_draws = cfg->max_draws > 0 ? cfg->max_draws
-                                      : (int)std::fmax(64.0 * cfg->max_iterations, 8.0 * cfg->fixed_iterations);
-    const double thr = cfg->acc * cfg->acc;
-    const int norm = cfg->norm ? cfg->norm : SLAM_NORM_HAMMING2;
-    const int D0 = b.D0, W0 = b.W0;
+    sh.rp.prob = cfg->prob;
+    sh.rp.max_iterations = cfg->max_iterations;
+    sh.rp.fixed_iterations = cfg->fixed_iterations;
+    sh.rp.max_draws = cfg->max_draws > 0 ? cfg->max_draws
+                                         : (int)std::fmax(64.0 * cfg->max_iterations, 8.0 * cfg->fixed_iterations);
+    sh.thr = cfg->acc * cfg->acc;
+    sh.norm = cfg->norm ? cfg->norm : SLAM_NORM_HAMMING2;
 
-    // ---- 1. matching: F stereo + P temporal problems in one launch ----
-    for (int f = 0; f < F; ++f) {
-        b.h_prob[f] = 2 * f;
-        b.h_prob[F + P + f] = 2 * f + 1;
+    // ---- plan: the whole shard in one lane on the caller's stream, or chunks pipelined over two side streams ----
+    std::vector<Chunk> chunks = plan_chunks(io, cfg->pipeline_chunks);
+    int lane_F = 0, lane_P = 0;
+    for (const Chunk &c : chunks) {
+        lane_F = std::max(lane_F, c.hi - c.lo);
+        lane_P = std::max(lane_P, c.e - c.a);
     }
-    for (int p = 0; p < P; ++p) {
-        b.h_prob[F + p] = 2 * io->h_pair_f0[p];
-        b.h_prob[F + P + F + p] = 2 * io->h_pair_f1[p];
+    if (!chunks.empty()) {
+        const size_t dl = lane_bytes(lane_F, lane_P, N, cfg, false), hl = lane_bytes(lane_F, lane_P, N, cfg, true);
+        if (2 * dl > io->d_workspace_bytes || 2 * hl > io->h_workspace_bytes) chunks.clear();   // pairs not local in time
     }
-    SLAM_HIP_CHECK(hipMemcpyAsync(b.prob_q, b.h_prob, sizeof(int32_t) * (F + P), hipMemcpyHostToDevice, st));
-    SLAM_HIP_CHECK(hipMemcpyAsync(b.prob_t, b.h_prob + F + P, sizeof(int32_t) * (F + P), hipMemcpyHostToDevice, st));
-    SLAM_HIP_CHECK(hipMemcpyAsync(b.pair_f0, io->h_pair_f0, sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
-    SLAM_HIP_CHECK(hipMemcpyAsync(b.pair_f1, io->h_pair_f1, sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
-    SLAM_HIP_CHECK(hipEventRecord(g_ev[0], st));
-    // stereo_key and temporal_key are adjacent carve-outs only up to alignment, so two launches share no buffer;
-    // one launch over a contiguous key array would need F*N == aligned offset: keep it simple, launch twice.
-    int rc = slam_match_hamming_batched(io->d_desc, io->d_count, N, b.prob_q, b.prob_t, F, norm, SLAM_MATCH_CROSSCHECK,
-                                        b.stereo_key, nullptr, st);
-    if (rc) return rc;
-    rc = slam_match_hamming_batched(io->d_desc, io->d_count, N, b.prob_q + F, b.prob_t + F, P, norm,
-                                    SLAM_MATCH_CROSSCHECK, b.temporal_key, nullptr, st);
-    if (rc) return rc;
-    SLAM_HIP_CHECK(hipEventRecord(g_ev[1], st));
-
-    // ---- host, while the GPU matches: raw MT19937 words of every pair's stream ----
-    const double t_rng0 = now_ms();
-    parallel_for(P, 64, [&](int a, int e) {
-        for (int p = a; p < e; ++p) slam_mt_seed_words(io->h_pair_seed[p], b.h_words0 + (size_t)p * W0, W0);
-    });
-    double host_ms = now_ms() - t_rng0;
-    SLAM_HIP_CHECK(hipMemcpyAsync(b.words0, b.h_words0, sizeof(uint32_t) * (size_t)P * W0, hipMemcpyHostToDevice, st));
-
-    // ---- 2. join, 3. triangulate ----
-    rc = slam_launch_rect_join(io->d_xy, io->d_count, N, b.stereo_key, b.temporal_key, b.pair_f0, b.pair_f1, P,
-                               cfg->rec_err, b.tcount, io->d_tracked_kp, b.xy0, b.xy1, b.aux, st);
-    if (rc) return rc;
-    SLAM_HIP_CHECK(hipEventRecord(g_ev[2], st));
-    rc = slam_launch_triangulate(Pm, Qm, b.xy0, b.tcount, P, N, b.X, st);
-    if (rc) return rc;
-    SLAM_HIP_CHECK(hipEventRecord(g_ev[3], st));
-
-    // ---- 4. RANSAC round 0: D0 speculative draws for every pair ----
-    rc = slam_launch_map_samples(b.words0, W0, b.tcount, nullptr, P, D0, b.sample0, b.produced0, st);
-    if (rc) return rc;
-    rc = slam_launch_p3p(K, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.sample0, D0, 0, D0, b.pose0, b.status0, st);
-    if (rc) return rc;
-    rc = slam_launch_score(K, M2, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.pose0, b.status0, D0, thr, b.cnt0, nullptr, st);
-    if (rc) return rc;
-    SLAM_HIP_CHECK(hipMemcpyAsync(b.h_tcount, b.tcount, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
-    SLAM_HIP_CHECK(hipMemcpyAsync(b.h_aux, b.aux, sizeof(int32_t) * 2 * P, hipMemcpyDeviceToHost, st));
-    SLAM_HIP_CHECK(hipMemcpyAsync(b.h_produced0, b.produced0, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
-    SLAM_HIP_CHECK(hipMemcpyAsync(b.h_status0, b.status0, (size_t)P * D0, hipMemcpyDeviceToHost, st));
-    SLAM_HIP_CHECK(hipMemcpyAsync(b.h_cnt0, b.cnt0, sizeof(int32_t) * (size_t)P * D0, hipMemcpyDeviceToHost, st));
-    SLAM_HIP_CHECK(hipStreamSynchronize(st));
-
-    double t_h0 = now_ms();
-    std::vector<RansacReplay> rs(P);
-    std::vector<int> active;
-    for (int p = 0; p < P; ++p) {
-        RansacReplay &r = rs[p];
-        const int n = b.h_tcount[p];
-        if (n <= 0) {
-            r.finished = true;
-        } else {
-            r.consume(rp, n, b.h_status0 + (size_t)p * D0, b.h_cnt0 + (size_t)p * D0, 0, b.h_produced0[p]);
+    Lane *L = g_lane;
+    if (!g_base) SLAM_HIP_CHECK(hipEventCreate(&g_base));
+    SLAM_HIP_CHECK(hipEventRecord(g_base, st));
+    for (int k = 0; k < 2; ++k) {
+        L[k].host_ms = 0;
+        L[k].base = g_base;
+        L[k].match_iv.clear();
+        for (double &v : L[k].stage_ms) v = 0;
+    }
+    int n_launch = 0;
+    if (chunks.empty()) {
+        Carver dc(io->d_workspace), hc(io->h_workspace);
+        layout(F, P, N, cfg, dc, hc, L[0].b);
+        if (dc.off > io->d_workspace_bytes || hc.off > io->h_workspace_bytes) {
+            slam_set_error("slam_track_pairs: workspace too small (device %zu < %zu or host %zu < %zu)",
+                           io->d_workspace_bytes, dc.off, io->h_workspace_bytes, hc.off);
+            return SLAM_E_WORKSPACE;
         }
-        b.h_best_idx[p] = r.best_draw;
-        if (!r.finished) active.push_back(p);
-    }
-    host_ms += now_ms() - t_h0;
-    SLAM_HIP_CHECK(hipMemsetAsync(b.best_status, 0, P, st));
-    SLAM_HIP_CHECK(hipMemsetAsync(b.best_pose, 0xFF, sizeof(double) * 12 * (size_t)P, st));   // NaN pattern
-    SLAM_HIP_CHECK(hipMemcpyAsync(b.best_idx, b.h_best_idx, sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(gather_best_kernel, dim3(slam_div_up((long)P * 12, 256)), dim3(256), 0, st, b.pose0, b.status0,
-                       b.best_idx, nullptr, P, D0, b.best_pose, b.best_status);
-    SLAM_HIP_CHECK(hipGetLastError());
-
-    // ---- later rounds for the pairs whose loop wanted more draws than were evaluated ----
-    // The host now knows every pair's point count, so it draws the sample indices itself (same stream, restarted
-    // from the pair's seed) and uploads only the new range [draws consumed so far, + n_eval).
-    long n_eval_l = (long)D0 * 8;
-    while (!active.empty()) {
-        if (n_eval_l > HYP_BUDGET) n_eval_l = HYP_BUDGET;
-        const int n_eval = (int)n_eval_l;
-        int rows_per_batch = (int)(HYP_BUDGET / n_eval);
-        if (rows_per_batch > b.RB) rows_per_batch = b.RB;
-        std::vector<int> still;
-        for (size_t a0 = 0; a0 < active.size(); a0 += rows_per_batch) {
-            const int rows = (int)std::min<size_t>(rows_per_batch, active.size() - a0);
-            t_h0 = now_ms();
-            parallel_for(rows, 1, [&](int a, int e) {
-                std::vector<int32_t> tmp;
-                for (int r = a; r < e; ++r) {
-                    const int p = active[a0 + r];
-                    const long begin = rs[p].draws, total = (begin + n_eval) * 4;
-                    tmp.resize(total);
-                    slam_randint_host(io->h_pair_seed[p], (uint32_t)b.h_tcount[p], tmp.data(), total);
-                    std::memcpy(b.h_sampleR + (size_t)r * n_eval * 4, tmp.data() + begin * 4, sizeof(int32_t) * (size_t)n_eval * 4);
-                }
-            });
-            for (int r = 0; r < rows; ++r) b.h_seg_of[r] = active[a0 + r];
-            host_ms += now_ms() - t_h0;
-            SLAM_HIP_CHECK(hipMemcpyAsync(b.seg_of, b.h_seg_of, sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
-            SLAM_HIP_CHECK(hipMemcpyAsync(b.sampleR, b.h_sampleR, sizeof(int32_t) * (size_t)rows * n_eval * 4, hipMemcpyHostToDevice, st));
-            rc = slam_launch_p3p(K, b.X, b.xy1, 0, b.tcount, b.seg_of, rows, N, b.sampleR, n_eval, 0, n_eval, b.poseR, b.statusR, st);
-            if (rc) return rc;
-            rc = slam_launch_score(K, M2, b.X, b.xy1, 0, b.tcount, b.seg_of, rows, N, b.poseR, b.statusR, n_eval, thr, b.cntR, nullptr, st);
-            if (rc) return rc;
-            SLAM_HIP_CHECK(hipMemcpyAsync(b.h_statusR, b.statusR, (size_t)rows * n_eval, hipMemcpyDeviceToHost, st));
-            SLAM_HIP_CHECK(hipMemcpyAsync(b.h_cntR, b.cntR, sizeof(int32_t) * (size_t)rows * n_eval, hipMemcpyDeviceToHost, st));
-            SLAM_HIP_CHECK(hipStreamSynchronize(st));
-            t_h0 = now_ms();
-            for (int r = 0; r < rows; ++r) {
-                const int p = active[a0 + r];
-                RansacReplay &s = rs[p];
-                const int before = s.best_draw, begin = s.draws;
-                s.consume(rp, b.h_tcount[p], b.h_statusR + (size_t)r * n_eval, b.h_cntR + (size_t)r * n_eval, begin,
-                          begin + n_eval);
-                b.h_best_idxR[r] = s.best_draw != before ? s.best_draw - begin : -1;
-                if (!s.finished) still.push_back(p);
+        L[0].st = st;
+        L[0].set_chunk(sh, 0, P, 0, F);
+        int rc = L[0].front(sh);
+        if (!rc) rc = L[0].mid(sh);
+        if (!rc) rc = L[0].back(sh);
+        if (rc) return rc;
+        n_launch = 1;
+    } else {
+        if (!g_fork) {
+            SLAM_HIP_CHECK(hipEventCreateWithFlags(&g_fork, hipEventDisableTiming));
+            for (auto &s : g_side_stream) SLAM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        }
+        const size_t dl = lane_bytes(lane_F, lane_P, N, cfg, false), hl = lane_bytes(lane_F, lane_P, N, cfg, true);
+        SLAM_HIP_CHECK(hipEventRecord(g_fork, st));              // inputs were produced on the caller's stream
+        for (int k = 0; k < 2; ++k) {
+            Carver dc((char *)io->d_workspace + k * dl), hc((char *)io->h_workspace + k * hl);
+            layout(lane_F, lane_P, N, cfg, dc, hc, L[k].b);
+            L[k].st = g_side_stream[k];
+            SLAM_HIP_CHECK(hipStreamWaitEvent(L[k].st, g_fork, 0));
+        }
+        const int C = (int)chunks.size();
+        int rc = SLAM_OK;
+        for (int c = 0; c < 2 && c < C && !rc; ++c) {
+            L[c].set_chunk(sh, chunks[c].a, chunks[c].e, chunks[c].lo, chunks[c].hi);
+            rc = L[c].front(sh);
+        }
+        for (int c = 0; c < C && !rc; ++c) {
+            Lane &ln = L[c & 1];
+            rc = ln.mid(sh);                                     // the other lane's kernels keep the GPU busy meanwhile
+            if (!rc) rc = ln.back(sh);
+            if (!rc && c + 2 < C) {
+                ln.set_chunk(sh, chunks[c + 2].a, chunks[c + 2].e, chunks[c + 2].lo, chunks[c + 2].hi);
+                rc = ln.front(sh);
             }
-            host_ms += now_ms() - t_h0;
-            SLAM_HIP_CHECK(hipMemcpyAsync(b.best_idxR, b.h_best_idxR, sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(gather_best_kernel, dim3(slam_div_up((long)rows * 12, 256)), dim3(256), 0, st, b.poseR,
-                               b.statusR, b.best_idxR, b.seg_of, rows, n_eval, b.best_pose, b.best_status);
-            SLAM_HIP_CHECK(hipGetLastError());
-            // the next sub-batch reuses the host staging buffers: drain before overwriting them
-            SLAM_HIP_CHECK(hipStreamSynchronize(st));
         }
-        active.swap(still);
-        n_eval_l *= 8;
-    }
-    SLAM_HIP_CHECK(hipEventRecord(g_ev[4], st));
-
-    // ---- 5. supporter mask of the winner (pre-refit, as the reference returns) + refit ----
-    rc = slam_launch_score(K, M2, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.best_pose, b.best_status, 1, thr, b.best_cnt, b.mask, st);
-    if (rc) return rc;
-    rc = slam_launch_refit(K, b.X, b.xy1, 0, b.tcount, P, N, b.mask, b.best_pose, b.refit_pose, b.refit_status, st);
-    if (rc) return rc;
-    SLAM_HIP_CHECK(hipEventRecord(g_ev[5], st));
-    SLAM_HIP_CHECK(hipMemcpyAsync(io->h_pose, b.refit_pose, sizeof(double) * 12 * (size_t)P, hipMemcpyDeviceToHost, st));
-    SLAM_HIP_CHECK(hipMemcpyAsync(io->h_mask, b.mask, sizeof(uint64_t) * (size_t)P * (N / 64), hipMemcpyDeviceToHost, st));
-    SLAM_HIP_CHECK(hipMemcpyAsync(b.h_best_cnt, b.best_cnt, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
-    SLAM_HIP_CHECK(hipMemcpyAsync(b.h_refit_status, b.refit_status, P, hipMemcpyDeviceToHost, st));
-    SLAM_HIP_CHECK(hipStreamSynchronize(st));
-
-    for (int p = 0; p < P; ++p) {
-        const RansacReplay &r = rs[p];
-        int32_t *s = io->h_stats + (size_t)p * 8;
-        const int n = b.h_tcount[p];
-        int status = 0;
-        if (n <= 0) status |= SLAM_PAIR_EMPTY;
-        if (r.hit_cap) status |= SLAM_PAIR_DRAW_CAP;
-        if (n > 0 && !b.h_refit_status[p]) status |= SLAM_PAIR_FEW;
-        if (b.h_refit_status[p]) status |= SLAM_PAIR_OK;
-        s[0] = n;
-        s[1] = n > 0 && r.best_draw >= 0 ? b.h_best_cnt[p] : 0;
-        s[2] = r.it;
-        s[3] = r.draws;
-        s[4] = r.best_draw;
-        s[5] = status;
-        s[6] = b.h_aux[2 * p];
-        s[7] = b.h_aux[2 * p + 1];
-        if (n <= 0) {   // refit kernel saw count 0 and wrote NaN already; the mask rows are zero
-            for (int k = 0; k < 12; ++k) io->h_pose[(size_t)p * 12 + k] = std::nan("");
+        if (rc) {
+            hipStreamSynchronize(g_side_stream[0]);
+            hipStreamSynchronize(g_side_stream[1]);
+            return rc;
         }
+        n_launch = C;
     }
-    float ms = 0;
-    for (int k = 0; k < 5; ++k) {
-        hipEventElapsedTime(&ms, g_ev[k], g_ev[k + 1]);
-        g_timing[k] = ms;
+    for (int k = 0; k < 5; ++k) g_timing[k] = L[0].stage_ms[k] + L[1].stage_ms[k];
+    {   // matching: union of the launch intervals (with two lanes the per-launch durations overlap in time)
+        std::vector<std::pair<float, float>> iv = L[0].match_iv;
+        iv.insert(iv.end(), L[1].match_iv.begin(), L[1].match_iv.end());
+        g_timing[0] = union_ms(iv);
     }
     g_timing[5] = now_ms() - t_begin;
-    g_timing[6] = host_ms;
-    g_timing[7] = 2;
+    g_timing[6] = L[0].host_ms + L[1].host_ms;
+    g_timing[7] = n_launch;
     return SLAM_OK;
 }

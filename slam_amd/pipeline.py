@@ -51,15 +51,21 @@ def _track_config(cfg: HotPathConfig) -> _lib.SlamTrackConfig:
 
 
 class ShardTracker:
-    """Owns the device/pinned workspaces for shards of up to (n_frames, n_pairs, n_max) and runs them."""
+    """Owns the device/pinned workspaces for shards of up to (n_frames, n_pairs, n_max) and runs them.
 
-    def __init__(self, n_frames: int, n_pairs: int, n_max: int, cfg: HotPathConfig | None = None):
+    n_chunks > 1 asks the library to split the pair list into contiguous blocks and pipeline them over two internal
+    HIP streams, so the latency-bound RANSAC rounds (small kernels, host replay, D2H syncs) of one block overlap the
+    VALU-bound matching of the next.  Results are identical to n_chunks = 1: every pair's computation is independent
+    of which block carries it."""
+
+    def __init__(self, n_frames: int, n_pairs: int, n_max: int, cfg: HotPathConfig | None = None, n_chunks: int = 1):
         self.cfg = cfg or HotPathConfig()
         self.n_frames, self.n_pairs, self.n_max = n_frames, n_pairs, n_max
         if n_max % 64:
             raise ValueError("n_max must be a multiple of 64")
         self.dev = ops.device()
         self._c = _track_config(self.cfg)
+        self._c.pipeline_chunks = max(1, int(n_chunks))
         L = _lib.lib()
         self.d_ws_bytes = L.slam_track_device_workspace_bytes(n_frames, n_pairs, n_max, ctypes.byref(self._c))
         self.h_ws_bytes = L.slam_track_host_workspace_bytes(n_frames, n_pairs, n_max, ctypes.byref(self._c))

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     import ctypes
-    assert ctypes.sizeof(_lib.SlamTrackConfig) == (9 + 12 + 12 + 4) * 8 + 4 * 4
+    assert ctypes.sizeof(_lib.SlamTrackConfig) == (9 + 12 + 12 + 4) * 8 + 6 * 4
     assert ctypes.sizeof(_lib.SlamTrackIO) % 8 == 0
 
 

@@ -287,3 +287,23 @@ def test_full_pipeline_against_oracle_sequence():
         assert err <= REL_TOL, (p, err)
         gt = seq.gt_relative(p + 1)
         assert np.abs(res.pose[p] - gt).max() < 0.05
+
+
+def test_chunked_two_stream_pipeline_equals_single_pass():
+    from slam_amd.pipeline import ShardTracker, consecutive_pairs
+    seq, desc, xy, count = _small_sequence(n_frames=12, n_features=300, seed=4)
+    F, _, n_max, _ = desc.shape
+    f0, f1 = consecutive_pairs(F)
+    seeds = 777 + np.arange(F - 1)
+    args = (dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)), f0, f1, seeds)
+    one = ShardTracker(F, F - 1, n_max).run(*args)
+    kp_one = one.tracked_kp.cpu().numpy().copy()
+    for n_chunks in (2, 3, 5):
+        many = ShardTracker(F, F - 1, n_max, n_chunks=n_chunks).run(*args)
+        assert np.array_equal(many.stats[:, :5], one.stats[:, :5])
+        assert np.array_equal(many.mask, one.mask)
+        assert np.array_equal(many.pose, one.pose, equal_nan=True)
+        T = one.stats[:, 0]
+        kp_many = many.tracked_kp.cpu().numpy()
+        for p in range(F - 1):
+            assert np.array_equal(kp_many[p, :T[p]], kp_one[p, :T[p]])
