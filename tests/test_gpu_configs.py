@@ -1,0 +1,141 @@
+"""BASELINE.json configurations beyond the default: full-size properties (config 2), the stress case (config 4:
+8k features, 60 % outliers, fixed hypothesis budget) and batched loop-closure validation (config 5)."""
+import numpy as np
+import pytest
+import torch
+
+import c_oracle
+import slam_oracle as orc
+from slam_amd import _lib
+from slam_amd.config import HotPathConfig
+from slam_amd.pipeline import ShardTracker, compose_global, consecutive_pairs
+from slam_amd.synth import SynthConfig, SynthSequence
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-5
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _frame(desc, xy, count, i):
+    n0, n1 = count[i]
+    return dict(dsc_l=desc[i, 0, :n0, :61], dsc_r=desc[i, 1, :n1, :61], xy_l=xy[i, 0, :n0], xy_r=xy[i, 1, :n1])
+
+
+def _fast_oracle():
+    orc.bf_match = lambda a, b, norm=7: c_oracle.match_crosscheck_w64(c_oracle.pad64(a), c_oracle.pad64(b), norm)
+
+
+def test_full_size_sequence_properties():
+    """3450 frames x ~2000 features (BASELINE configs[1]): size-independent properties + oracle spot checks."""
+    _fast_oracle()
+    F = 3450
+    cfg = SynthConfig(n_frames=F, n_features=2000, seed=1234)
+    seq = SynthSequence(cfg)
+    desc, xy, count = seq.frames(0, F)
+    n_max = cfg.n_max
+    args = (dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)))
+    f0, f1 = consecutive_pairs(F)
+    seeds = 1000 + np.arange(F - 1)
+    res = ShardTracker(F, F - 1, n_max, n_chunks=2).run(*args, f0, f1, seeds)
+    kp = res.tracked_kp.cpu().numpy()
+    T = res.stats[:, 0]
+    assert res.ok.all() and (T > 500).all()
+    # determinism + independence from the chunking: a second pass, unchunked, is identical bit for bit
+    res1 = ShardTracker(F, F - 1, n_max, n_chunks=1).run(*args, f0, f1, seeds)
+    assert np.array_equal(res.pose, res1.pose) and np.array_equal(res.mask, res1.mask)
+    assert np.array_equal(res.stats[:, :5], res1.stats[:, :5])
+    for p in range(0, F - 1, 97):
+        k = kp[p, :T[p]]
+        assert (np.diff(k[:, 0]) > 0).all()                                  # ascending left0 key-point, no duplicates
+        assert len(np.unique(k[:, 2])) == len(k)                              # cross-check: injective into left1
+        assert (k[:, 0] < count[p, 0]).all() and (k[:, 1] < count[p, 1]).all()
+        assert (k[:, 2] < count[p + 1, 0]).all() and (k[:, 3] < count[p + 1, 1]).all()
+        assert (np.abs(xy[p, 0, k[:, 0], 1] - xy[p, 1, k[:, 1], 1]) <= 2).all()   # rectified-stereo test holds
+        assert not res.mask[p, T[p]:].any() and res.mask[p, :T[p]].sum() == res.stats[p, 1]
+    R = res.pose[:, :, :3]
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-9           # proper rotations
+    assert (res.stats[:, 2] <= 1000).all() and (res.stats[:, 3] >= res.stats[:, 2]).all()
+    assert (res.stats[:, 1] >= 0.8 * T).all()
+    # relative poses close to the generator's ground truth; composed trajectory drifts but stays sane
+    gt_rel = np.array([seq.gt_relative(i) for i in range(1, F)])
+    assert np.abs(res.pose - gt_rel).max() < 0.08
+    glob = compose_global(np.concatenate([np.eye(3, 4)[None], res.pose]))
+    assert np.isfinite(glob).all()
+    # oracle spot checks at full size (bit-exact sets and masks, 1e-5 poses)
+    for p in (0, 1723, F - 2):
+        np.random.seed(int(seeds[p]))
+        st = {}
+        with np.errstate(all="ignore"):
+            want = orc.track_pair(_frame(desc, xy, count, p), _frame(desc, xy, count, p + 1), stats=st)
+        n = len(want["kp"])
+        assert T[p] == n and np.array_equal(kp[p, :n], want["kp"])
+        assert np.array_equal(res.mask[p, :n], want["mask"])
+        assert res.stats[p, 2] == st["iterations"] and res.stats[p, 4] == st["best_draw"]
+        assert np.linalg.norm(res.pose[p] - want["T"]) / np.linalg.norm(want["T"]) <= REL_TOL
+
+
+def test_stress_8k_features_60pct_outliers_fixed_hypotheses():
+    """BASELINE configs[3] at a hypothesis budget the oracle finishes in seconds (1500 instead of 10 000)."""
+    _fast_oracle()
+    cfg = SynthConfig(n_frames=40, n_features=8000, true_frac=0.4, seed=5, spawn_per_frame=400, mismatch_frac=0.3,
+                      gross_frac=0.15, ragged=31)
+    seq = SynthSequence(cfg)
+    F = 2
+    desc, xy, count = seq.frames(10, 10 + F)
+    n_max = cfg.n_max
+    hp = HotPathConfig(fixed_iterations=1500)
+    res = ShardTracker(F, 1, n_max, hp).run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)),
+                                            dev(count.reshape(2 * F)), np.array([0]), np.array([1]), np.array([424242]))
+    kp = res.tracked_kp.cpu().numpy()
+    np.random.seed(424242)
+    st = {}
+    with np.errstate(all="ignore"):
+        want = orc.track_pair(_frame(desc, xy, count, 0), _frame(desc, xy, count, 1), stats=st, fixed_iterations=1500)
+    n = len(want["kp"])
+    assert n > 800 and res.stats[0, 0] == n and np.array_equal(kp[0, :n], want["kp"])
+    assert res.stats[0, 2] == 1500 == st["iterations"]
+    assert res.stats[0, 3] == st["draws"] and res.stats[0, 4] == st["best_draw"]
+    assert np.array_equal(res.mask[0, :n], want["mask"])
+    assert 0.3 < want["mask"].mean() < 0.95                                    # a genuinely contaminated set
+    assert np.linalg.norm(res.pose[0] - want["T"]) / np.linalg.norm(want["T"]) <= REL_TOL
+
+
+def test_loop_closure_candidates_batched():
+    """BASELINE configs[4]: every frame against 5 candidate frames (2 near revisits, 3 unrelated) in one device pass."""
+    _fast_oracle()
+    cfg = SynthConfig(n_frames=400, n_features=600, seed=17, spawn_per_frame=60, ragged=23)
+    seq = SynthSequence(cfg)
+    movie = list(range(0, 30)) + list(range(300, 330))          # two stretches of the drive 200 m apart
+    F = len(movie)
+    fr = [seq.frame(i) for i in movie]
+    desc, xy, count = (np.array([f[k] for f in fr]) for k in ("desc", "xy", "count"))
+    n_max = cfg.n_max
+    rng = np.random.default_rng(3)
+    cur, cand = [], []
+    for f in range(36, F):                                       # current frames in the second stretch
+        for c in (f - 2, f - 5, *rng.integers(0, 30, 3)):        # 2 revisits + 3 frames of the first stretch (utills.py:1128)
+            cand.append(int(c))
+            cur.append(f)
+    pair_f0, pair_f1 = np.array(cand, np.int32), np.array(cur, np.int32)
+    P = len(cur)
+    seeds = 9000 + np.arange(P)
+    res = ShardTracker(F, P, n_max).run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)),
+                                        dev(count.reshape(2 * F)), pair_f0, pair_f1, seeds)
+    kp = res.tracked_kp.cpu().numpy()
+    perc = res.inliers_percentage()
+    near = np.arange(P) % 5 < 2
+    assert (perc[near & (res.stats[:, 0] > 30)] > 85).mean() > 0.9            # revisits pass the reference's threshold (PoseGraph.py:24)
+    # unrelated frames still yield ~25 % spurious 4-view tracks (the cross-check rule is not mutual); RANSAC rejects them
+    assert (perc[~near] < 30).all()
+    assert (res.stats[:, 5] & (_lib.SLAM_PAIR_EMPTY | _lib.SLAM_PAIR_FEW | _lib.SLAM_PAIR_OK) != 0).all()
+    for p in (0, 1, 56, P - 4):
+        np.random.seed(int(seeds[p]))
+        with np.errstate(all="ignore"):
+            want = orc.track_pair(_frame(desc, xy, count, pair_f0[p]), _frame(desc, xy, count, pair_f1[p]))
+        n = len(want["kp"])
+        assert res.stats[p, 0] == n and np.array_equal(kp[p, :n], want["kp"])
+        assert np.array_equal(res.mask[p, :n], want["mask"])
+        assert np.linalg.norm(res.pose[p] - want["T"]) / np.linalg.norm(want["T"]) <= REL_TOL
