@@ -279,16 +279,19 @@ struct Lane {
         double t_h0 = now_ms();
         rs.assign(P, RansacReplay());
         active.clear();
-        for (int p = 0; p < P; ++p) {
-            RansacReplay &r = rs[p];
-            const int n = b.h_tcount[p];
-            if (n <= 0)
-                r.finished = true;
-            else
-                r.consume(rp, n, b.h_status0 + (size_t)p * D0, b.h_cnt0 + (size_t)p * D0, 0, b.h_produced0[p]);
-            b.h_best_idx[p] = r.best_draw;
-            if (!r.finished) active.push_back(p);
-        }
+        parallel_for(P, 256, [&](int a, int e) {         // pairs are independent: replay them on all host cores
+            for (int p = a; p < e; ++p) {
+                RansacReplay &r = rs[p];
+                const int n = b.h_tcount[p];
+                if (n <= 0)
+                    r.finished = true;
+                else
+                    r.consume(rp, n, b.h_status0 + (size_t)p * D0, b.h_cnt0 + (size_t)p * D0, 0, b.h_produced0[p]);
+                b.h_best_idx[p] = r.best_draw;
+            }
+        });
+        for (int p = 0; p < P; ++p)
+            if (!rs[p].finished) active.push_back(p);
         host_ms += now_ms() - t_h0;
         SLAM_HIP_CHECK(hipMemsetAsync(b.best_status, 0, P, st));
         SLAM_HIP_CHECK(hipMemsetAsync(b.best_pose, 0xFF, sizeof(double) * 12 * (size_t)P, st));   // NaN pattern

@@ -20,7 +20,7 @@ __device__ __forceinline__ void dlt_point(const Mat34 &P, const Mat34 &Q, double
         A[2][j] = xr * Q.m[8 + j] - Q.m[j];
         A[3][j] = yr * Q.m[8 + j] - Q.m[4 + j];
     }
-    jacobi_onesided<4>(A, V);
+    jacobi4(A, V);
     double best = 0;
     int k = 0;
 #pragma unroll
