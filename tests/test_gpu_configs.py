@@ -139,3 +139,41 @@ def test_loop_closure_candidates_batched():
         assert res.stats[p, 0] == n and np.array_equal(kp[p, :n], want["kp"])
         assert np.array_equal(res.mask[p, :n], want["mask"])
         assert np.linalg.norm(res.pose[p] - want["T"]) / np.linalg.norm(want["T"]) <= REL_TOL
+
+
+def test_degenerate_frames_empty_and_tiny():
+    """Edge cases the reference handles by raising / returning None: a frame without features (tracked set empty ->
+    ValueError at utills.py:502) and a frame with 3 features (fewer than 6 supporters -> pose None, :558-559)."""
+    _fast_oracle()
+    cfg = SynthConfig(n_frames=40, n_features=300, seed=2, spawn_per_frame=40, ragged=13)
+    seq = SynthSequence(cfg)
+    F = 6
+    desc, xy, count = seq.frames(0, F)
+    count = count.copy()
+    count[2] = 0                      # frame 2: nothing detected
+    count[4] = 3                      # frame 4: three features per image
+    n_max = cfg.n_max
+    f0, f1 = consecutive_pairs(F)
+    seeds = 50 + np.arange(F - 1)
+    res = ShardTracker(F, F - 1, n_max).run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)),
+                                            dev(count.reshape(2 * F)), f0, f1, seeds)
+    st = res.stats
+    assert st[0, 5] & _lib.SLAM_PAIR_OK
+    for p in (1, 2):                                              # pairs touching the empty frame
+        assert st[p, 0] == 0 and st[p, 5] & _lib.SLAM_PAIR_EMPTY and np.isnan(res.pose[p]).all() and not res.mask[p].any()
+    for p in (3, 4):                                              # pairs touching the 3-feature frame
+        assert st[p, 0] <= 3 and np.isnan(res.pose[p]).all()
+        assert st[p, 5] & (_lib.SLAM_PAIR_FEW | _lib.SLAM_PAIR_EMPTY)
+        if st[p, 0] > 0:
+            np.random.seed(int(seeds[p]))
+            stt = {}
+            with np.errstate(all="ignore"):
+                want = orc.track_pair(_frame(desc, xy, count, p), _frame(desc, xy, count, p + 1), stats=stt)
+            assert want["T"] is None and st[p, 2] == stt["iterations"] == 1000 and st[p, 3] == stt["draws"]
+            assert np.array_equal(res.mask[p, :st[p, 0]], want["mask"])
+    # the healthy pair is untouched by its neighbours
+    np.random.seed(int(seeds[0]))
+    with np.errstate(all="ignore"):
+        want = orc.track_pair(_frame(desc, xy, count, 0), _frame(desc, xy, count, 1))
+    assert np.array_equal(res.mask[0, :st[0, 0]], want["mask"])
+    assert np.linalg.norm(res.pose[0] - want["T"]) / np.linalg.norm(want["T"]) <= REL_TOL
