@@ -147,6 +147,7 @@ def main():
             "hbm_algorithmic_GBps": round(alg_bytes / (m_ms * 1e-3) / 1e9, 2), "hbm_peak_GBps": HBM_PEAK_GBPS,
             "traffic": None,
         }
+        roofline.update(pmc_traffic(args))
         # trajectory sanity: ATE of the composed trajectory against the generator's ground truth
         centres = pipeline.camera_centres(glob)
         gt = np.array([-seq.R_cw[i].T @ seq.t_cw[i] for i in range(F)])
@@ -177,6 +178,24 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(args):
+    """HBM bytes per matcher launch from the committed PMC passes (tools/profile_gpu.sh: separate FETCH_SIZE and
+    WRITE_SIZE runs of this same workload, one launch per step; FETCH_SIZE doubled as the gfx950 guide prescribes).
+    PMC counters cannot be collected from inside a timed run, so the figure is the profile's, valid only for the
+    default workload; any other size reports null."""
+    path = os.path.join(ROOT, "profiles", "r1_final_pmc_summary.json")
+    if (args.frames, args.features, args.seed) != (3450, 2000, 1234) or not os.path.exists(path):
+        return {}
+    with open(path) as fh:
+        pmc = json.load(fh)
+    for name, e in pmc.items():
+        if name.startswith("allpairs_top2_kernel") and "hbm_read_bytes_per_dispatch_corrected" in e:
+            rd, wr = e["hbm_read_bytes_per_dispatch_corrected"], e.get("hbm_write_bytes_per_dispatch", 0)
+            return {"traffic": rd + wr, "traffic_unit": "bytes per whole-shard launch (PMC read x2 + write)",
+                    "traffic_source": "profiles/r1_final_pmc_summary.json"}
+    return {}
 
 
 def cpu_baseline(args, seq, desc, xy, count, seeds, res, trk):
