@@ -1,0 +1,200 @@
+"""Host -> device ingest of detections: the step in front of the hot path.
+
+The reference detects on the CPU, one frame at a time (utils/utills.py:46-54 `detect_and_compute`, called from :393 and
+:839-845), and hands Python lists of cv2.KeyPoint plus an ndarray of descriptors straight to the matcher.  The device
+path wants whole shards instead, so the hand-over format is three packed arrays per shard of F frames
+
+    desc  uint8  [2F][n_max][64]   61-byte AKAZE rows (32 for ORB) zero-padded to 64 B; image 2f = left of frame f
+    xy    float32[2F][n_max][2]    KeyPoint.pt (cv2 key-points are float32)
+    count int32  [2F]              rows in use per image
+
+held in PINNED host memory that the detector workers fill in place (`ShardStager.host_slot`), and moved with one
+asynchronous copy per array on a dedicated HIP stream.  Two host slots and two device slots alternate, so shard s+1 is
+detected / packed / uploaded while shard s is being tracked; consecutive shards share one halo frame so that every
+consecutive frame pair belongs to exactly one shard (same partition as slam_amd/dist.py).
+
+Nothing here computes on the detections: the arithmetic stays in libslam_amd.  torch is used for pinned memory,
+streams and events only.
+"""
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import ops, pipeline
+from .config import HotPathConfig
+
+ROW_BYTES = 64
+
+
+def round_n_max(n: int) -> int:
+    """Per-image slot size: the largest feature count rounded up to the 64 rows the kernels tile by."""
+    return max(64, (int(n) + 63) // 64 * 64)
+
+
+def pack_image(desc_out: np.ndarray, xy_out: np.ndarray, pts, dsc) -> int:
+    """Writes one image's detections into its slot (desc_out uint8[n_max,64], xy_out float32[n_max,2]) and returns
+    the row count.  pts: sequence of (x, y) or float array [n,2]; dsc: uint8[n, <=64] or None (cv2 returns None for an
+    image without key-points, utils/utills.py:52-53).  Rows past the count and bytes past the descriptor width are
+    zeroed: the slot is reused and the padding must stay distance-neutral."""
+    n = 0 if dsc is None else len(dsc)
+    n_max = desc_out.shape[0]
+    if n > n_max:
+        raise ValueError(f"{n} detections do not fit a slot of {n_max} rows")
+    if n:
+        d = np.asarray(dsc, dtype=np.uint8)
+        if d.ndim != 2 or d.shape[1] > ROW_BYTES:
+            raise ValueError("descriptors must be uint8[n, <=64]")
+        w = d.shape[1]
+        desc_out[:n, :w] = d
+        desc_out[:n, w:] = 0
+        xy_out[:n] = np.asarray(pts, dtype=np.float32).reshape(n, 2)
+    desc_out[n:] = 0
+    xy_out[n:] = 0
+    return n
+
+
+@dataclass
+class HostSlot:
+    desc: np.ndarray     # uint8  [F, 2, n_max, 64]  views of pinned memory
+    xy: np.ndarray       # float32[F, 2, n_max, 2]
+    count: np.ndarray    # int32  [F, 2]
+
+
+class ShardStager:
+    """Two pinned host slots + two device slots for shards of up to n_frames frames, and the copy stream between them.
+
+        st = ShardStager(F, n_max)
+        slot = st.host_slot(k)                 # detector workers write slot.desc / .xy / .count in place
+        st.upload(k, n_frames)                 # async H2D on the copy stream (returns at once)
+        desc, xy, count = st.device(k)         # the compute stream waits for the copy; tensors are views of slot k
+        ... ShardTracker.run(desc, xy, count, ...)
+        st.release(k)                          # the next upload into slot k waits for the compute stream
+
+    Device memory: 2 x (2F x n_max x 72 B + 8F) - 2 GB for two 3450-frame shards of 2048-row images."""
+
+    def __init__(self, n_frames: int, n_max: int, n_slots: int = 2):
+        if n_max % 64:
+            raise ValueError("n_max must be a multiple of 64")
+        self.n_frames, self.n_max, self.n_slots = n_frames, n_max, n_slots
+        self.dev = ops.device()
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        F = n_frames
+        self._h, self._d, self._views = [], [], []
+        for _ in range(n_slots):
+            h = (torch.zeros((2 * F, n_max, ROW_BYTES), dtype=torch.uint8).pin_memory(),
+                 torch.zeros((2 * F, n_max, 2), dtype=torch.float32).pin_memory(),
+                 torch.zeros((2 * F,), dtype=torch.int32).pin_memory())
+            d = tuple(torch.empty(t.shape, dtype=t.dtype, device=self.dev) for t in h)
+            self._h.append(h)
+            self._d.append(d)
+            self._views.append(HostSlot(h[0].numpy().reshape(F, 2, n_max, ROW_BYTES), h[1].numpy().reshape(F, 2, n_max, 2),
+                                        h[2].numpy().reshape(F, 2)))
+        self._uploaded = [torch.cuda.Event() for _ in range(n_slots)]
+        self._released = [None] * n_slots
+        self._frames = [0] * n_slots
+
+    def host_slot(self, k: int) -> HostSlot:
+        return self._views[k % self.n_slots]
+
+    def bytes_per_shard(self, n_frames: int | None = None) -> int:
+        F = self.n_frames if n_frames is None else n_frames
+        return 2 * F * self.n_max * (ROW_BYTES + 8) + 2 * F * 4
+
+    def upload(self, k: int, n_frames: int | None = None) -> None:
+        k %= self.n_slots
+        F = self.n_frames if n_frames is None else int(n_frames)
+        if not 0 < F <= self.n_frames:
+            raise ValueError("shard larger than the stager's slots")
+        with torch.cuda.stream(self.copy_stream):
+            if self._released[k] is not None:
+                self.copy_stream.wait_event(self._released[k])     # compute still reading the device slot
+            for h, d in zip(self._h[k], self._d[k]):
+                d[:2 * F].copy_(h[:2 * F], non_blocking=True)
+            self._uploaded[k].record(self.copy_stream)
+        self._frames[k] = F
+
+    def device(self, k: int):
+        k %= self.n_slots
+        F = self._frames[k]
+        if F == 0:
+            raise RuntimeError("slot was never uploaded")
+        torch.cuda.current_stream(self.dev).wait_event(self._uploaded[k])
+        d = self._d[k]
+        return d[0][:2 * F], d[1][:2 * F], d[2][:2 * F]
+
+    def release(self, k: int) -> None:
+        k %= self.n_slots
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self._released[k] = ev
+
+    def host_ready(self, k: int) -> None:
+        """Blocks until the last upload of slot k has left the pinned buffer, i.e. the workers may overwrite it."""
+        self._uploaded[k % self.n_slots].synchronize()
+
+
+def shard_ranges(n_frames_total: int, frames_per_shard: int):
+    """[(first frame, one past last frame)] with a one-frame halo between neighbours: pairs (f, f+1) of shard s are
+    first <= f < last-1, so every consecutive pair of the movie falls in exactly one shard."""
+    if frames_per_shard < 2:
+        raise ValueError("a shard needs at least two frames")
+    out, a = [], 0
+    while a < n_frames_total - 1:
+        b = min(a + frames_per_shard, n_frames_total)
+        out.append((a, b))
+        a = b - 1
+    return out
+
+
+def fill_slot(slot: HostSlot, source, first: int, last: int, workers: int = 8) -> None:
+    """Packs frames [first, last) of a detection source (`get(i) -> (pts_l, dsc_l, pts_r, dsc_r)`, the shape of
+    utils/utills.py:46-54 applied to both images) into a host slot, one frame per task."""
+    def one(j):
+        pl, dl, pr, dr = source.get(first + j)
+        slot.count[j, 0] = pack_image(slot.desc[j, 0], slot.xy[j, 0], pl, dl)
+        slot.count[j, 1] = pack_image(slot.desc[j, 1], slot.xy[j, 1], pr, dr)
+    n = last - first
+    if workers <= 1 or n < 4:
+        for j in range(n):
+            one(j)
+    else:
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(one, range(n)))
+
+
+def track_movie_streamed(source, n_frames_total: int, n_max: int, frames_per_shard: int, cfg: HotPathConfig | None = None,
+                         seed_of_pair=None, n_chunks: int = 2, workers: int = 8):
+    """Whole-movie relative poses (find_features_in_consecutive_frames_whole_movie, utils/utills.py:834-873) for a movie
+    that is detected shard by shard: while shard s is tracked on the GPU the host packs and uploads shard s+1.
+    seed_of_pair(first_pair, n) -> uint32[n] gives np.random.seed values per pair (default 1000 + pair index).
+    Returns (pose float64[n-1,3,4], stats int32[n-1,8])."""
+    ranges = shard_ranges(n_frames_total, frames_per_shard)
+    Fm = max(b - a for a, b in ranges)
+    st = ShardStager(Fm, n_max)
+    trk = pipeline.ShardTracker(Fm, Fm - 1, n_max, cfg, n_chunks=n_chunks)
+    if seed_of_pair is None:
+        seed_of_pair = lambda first, n: 1000 + first + np.arange(n)
+    pose = np.full((n_frames_total - 1, 3, 4), np.nan)
+    stats = np.zeros((n_frames_total - 1, 8), np.int32)
+    with ThreadPoolExecutor(max_workers=1) as feeder:
+        def stage(s):
+            a, b = ranges[s]
+            st.host_ready(s)
+            fill_slot(st.host_slot(s), source, a, b, workers)
+            return s
+        pending = feeder.submit(stage, 0)
+        for s, (a, b) in enumerate(ranges):
+            pending.result()
+            st.upload(s, b - a)
+            if s + 1 < len(ranges):
+                pending = feeder.submit(stage, s + 1)          # packs the other slot while this shard runs
+            d_desc, d_xy, d_count = st.device(s)
+            f0, f1 = pipeline.consecutive_pairs(b - a)
+            res = trk.run(d_desc, d_xy, d_count, f0, f1, seed_of_pair(a, b - a - 1), unpack_mask=False)
+            st.release(s)
+            pose[a:b - 1], stats[a:b - 1] = res.pose, res.stats
+    return pose, stats
