@@ -149,10 +149,10 @@ def main():
             "traffic": None,
         }
         roofline.update(pmc_traffic(args))
-        # trajectory sanity: ATE of the composed trajectory against the generator's ground truth
-        centres = pipeline.camera_centres(glob)
-        gt = np.array([-seq.R_cw[i].T @ seq.t_cw[i] for i in range(F)])
-        ate = float(np.sqrt(np.mean(np.sum((centres - gt) ** 2, axis=1))))
+        # trajectory quality against the generator's ground truth (slam_amd/trajectory.py: the reference's
+        # between()/camera-centre series condensed into ATE / RPE), outside the timed region
+        from slam_amd import trajectory
+        traj = trajectory.summary(glob, np.array([seq.gt_global(i) for i in range(F)]))
         out = {
             "metric": "frame-pairs/sec (match+triangulate+PnP-RANSAC)", "value": round(value, 2), "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -167,7 +167,10 @@ def main():
                          "triangulate": round(float(stages[2]), 3), "ransac_rounds": round(float(stages[3]), 3),
                          "mask_refit": round(float(stages[4]), 3), "call_wall": round(float(stages[5]), 3),
                          "host_rng_replay": round(float(stages[6]), 3)},
-            "quality": {"ate_rmse_m_vs_ground_truth": round(ate, 4), "pairs_ok": int(res.ok.sum()), "pairs": P,
+            "quality": {"ate_rmse_m_vs_ground_truth": round(traj["ate_rmse_m"], 4),
+                        "end_drift_pct_of_path": round(traj["end_drift_pct_of_path"], 4),
+                        "rpe_trans_pct": round(traj["rpe_trans_pct"], 4),
+                        "rpe_rot_deg_per_m": round(traj["rpe_rot_deg_per_m"], 6), "pairs_ok": int(res.ok.sum()), "pairs": P,
                         "mean_tracked": round(float(res.tracked.mean()), 1),
                         "mean_supporters": round(float(res.supporters.mean()), 1),
                         "mean_iterations": round(float(res.stats[:, 2].mean()), 2)},

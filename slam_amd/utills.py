@@ -18,7 +18,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import _lib, ops, pipeline
+from . import _lib, ops, pipeline, trajectory
 from .config import BRUTE_FORCE, FLANN_KNN, NORM_HAMMING, NORM_HAMMING2, REGULAR_KNN, HotPathConfig
 from .synth import K_KITTI, M1_KITTI, M2_KITTI
 from .types import (DataBase, DMatch, Feature, Frame, KeyPoint, Track, dmatches_from_arrays, keypoints_from_xy,
@@ -430,6 +430,40 @@ def cameras_rel_pnp_est_and_ground_truth_locations(db, ground_truth=None):
     if ground_truth is None:
         raise ValueError("pass ground_truth: the KITTI poses file is not available")
     return left_cameras_trajectory([between(a, b) for a, b in zip(est, ground_truth)])
+
+
+def rot_mat_to_euler_angles(R_mat):
+    """:1072-1086."""
+    return trajectory.euler_angles(R_mat)
+
+
+def camera_angles(ex_cam_mat):
+    """:631-638."""
+    return rot_mat_to_euler_angles(ex_cam_mat[:, :3])
+
+
+def left_cameras_angles(global_trans):
+    """:821-830."""
+    return np.array([camera_angles(t) for t in global_trans])
+
+
+def translation_to_vec(translation):
+    """:1089-1094.  (euler angles, camera centre) as one 6-vector."""
+    R_mat, t_vec = translation[:, :3], translation[:, 3]
+    return np.hstack((rot_mat_to_euler_angles(R_mat), -R_mat.T @ t_vec))
+
+
+def cameras_rel_pnp_est_and_ground_truth_angles(db, ground_truth=None):
+    """:1211-1222.  Euler angles of R_est^T R_gt per frame; `ground_truth` replaces the KITTI poses file."""
+    if ground_truth is None:
+        raise ValueError("pass ground_truth: the KITTI poses file is not available")
+    est = convert_trans_from_rel_to_global(db.get_relative_cam_trans())
+    return trajectory.angle_errors(est, ground_truth)
+
+
+def trajectory_error_summary(db, ground_truth, delta=1):
+    """ATE / RPE figures of the PnP trajectory (no counterpart in the reference, which only plots the series above)."""
+    return trajectory.summary(convert_trans_from_rel_to_global(db.get_relative_cam_trans()), ground_truth, delta)
 
 
 # == Ex4: per-pair and whole-movie drivers ==
