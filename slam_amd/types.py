@@ -296,3 +296,130 @@ class DataBase:
     def tracks_median_len(self, percentage):
         lens = sorted(t.get_track_len() for t in self._tracks)
         return lens[int(percentage * len(lens))]
+
+
+class _LazyObjects:
+    """Sequence of objects made on first access; indexable like the numpy object arrays the reference keeps
+    (int, slice, integer array, boolean mask/list), so `tracks[frame.get_tracks_ids()]` keeps working."""
+
+    def __init__(self, n, make):
+        self._n, self._make, self._cache = n, make, {}
+
+    def __len__(self):
+        return self._n
+
+    def _one(self, i):
+        i = int(i)
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        o = self._cache.get(i)
+        if o is None:
+            o = self._cache[i] = self._make(i)
+        return o
+
+    def __iter__(self):
+        return (self._one(i) for i in range(self._n))
+
+    def __getitem__(self, key):
+        if isinstance(key, (int, np.integer)):
+            return self._one(key)
+        if isinstance(key, slice):
+            idx = range(*key.indices(self._n))
+        else:
+            key = np.asarray(key)
+            idx = np.nonzero(key)[0] if key.dtype == bool else key.reshape(-1)
+        out = np.empty(len(idx), dtype=object)
+        for j, i in enumerate(idx):
+            out[j] = self._one(i)
+        return out
+
+    def materialise(self):
+        return self[:]
+
+
+class ArrayFrame(Frame):
+    """Frame whose track ids stay an array until somebody appends to them."""
+
+    def __init__(self, id, ex_cam_mat, track_ids, calib_cam_mat=K_KITTI):
+        super().__init__(id, ex_cam_mat, calib_cam_mat)
+        self._tracks = track_ids
+
+    def add_track(self, track_id):
+        if not isinstance(self._tracks, list):
+            self._tracks = self._tracks.tolist()
+        self._tracks.append(track_id)
+
+
+class ArrayDataBase(DataBase):
+    """DataBase over a tracks.TrackTable: same accessors as DataBase (DataBase.py:155-328), objects made on demand.
+
+    Built straight from the hot path's index arrays (utills.whole_movie_database); equal, accessor by accessor, to
+    DataBase built from the materialised Feature lists."""
+
+    def __init__(self, table, kp_pairs, xy_frames, inliers_percentage, global_cam_trans, relative_cam_trans):
+        self._table = table
+        self._kp_pairs, self._xy_frames = kp_pairs, xy_frames
+        self._inliers_percentage = inliers_percentage
+        self._relative = np.array(relative_cam_trans)
+        self._last_kpts = {}
+        fp, ft = table.frame_ptr, table.frame_tracks
+        frames = np.empty(table.n_frames, dtype=object)
+        for f in range(table.n_frames):
+            frames[f] = ArrayFrame(f, global_cam_trans[f], ft[fp[f]:fp[f + 1]])
+        self._frames = frames
+        self._tracks = _LazyObjects(table.n_tracks, self._make_track)
+        self._pair_features = _LazyObjects(len(kp_pairs), self._make_pair_features)
+
+    def _feature(self, row):
+        t = self._table
+        kl, kr = t.obs_kp[row]
+        xl, xr, yl, yr = t.obs_xy[row]
+        return Feature(int(kl), int(kr), float(xl), float(xr), float(yl), float(yr))
+
+    def _make_track(self, tid):
+        t = self._table
+        tr = Track(tid)
+        for row in range(t.track_ptr[tid], t.track_ptr[tid + 1]):
+            tr.add_feature(int(t.obs_frame[row]), self._feature(row))
+        return tr
+
+    def _make_pair_features(self, i):
+        kp = self._kp_pairs[i]
+        out = []
+        for f, cols in ((i, (0, 1)), (i + 1, (2, 3))):
+            xl, xr = self._xy_frames[f][0], self._xy_frames[f][1]
+            a = np.empty(len(kp), dtype=object)
+            for j in range(len(kp)):
+                l, r = int(kp[j, cols[0]]), int(kp[j, cols[1]])
+                a[j] = Feature(l, r, float(xl[l, 0]), float(xr[r, 0]), float(xl[l, 1]), float(xr[r, 1]))
+            out.append(a)
+        return out
+
+    def get_table(self):
+        return self._table
+
+    def get_num_tracks(self):
+        return self._table.n_tracks
+
+    def get_tracks_with_specific_len(self, track_len):
+        return self._tracks[self._table.track_len() == track_len]
+
+    def tracks_median_len(self, percentage):
+        lens = np.sort(self._table.track_len())
+        return int(lens[int(percentage * len(lens))])
+
+    def get_rand_track(self, track_len):
+        """DataBase.py:293-305: same draws from `random` as the reference's loop, but only the winner is materialised;
+        where the reference would spin forever (no track of that length) this raises."""
+        lens = self._table.track_len()
+        if not (lens == track_len).any():
+            raise ValueError(f"no track of length {track_len}")
+        while True:
+            idx = random.randint(0, len(lens) - 1)
+            if lens[idx] == track_len:
+                return self._tracks[idx]
+
+    def add_track(self, track):
+        raise TypeError("ArrayDataBase is built whole; use DataBase to grow a database track by track")

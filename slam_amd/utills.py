@@ -18,10 +18,10 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import _lib, ops, pipeline, trajectory
+from . import _lib, ops, pipeline, tracks, trajectory
 from .config import BRUTE_FORCE, FLANN_KNN, NORM_HAMMING, NORM_HAMMING2, REGULAR_KNN, HotPathConfig
 from .synth import K_KITTI, M1_KITTI, M2_KITTI
-from .types import (DataBase, DMatch, Feature, Frame, KeyPoint, Track, dmatches_from_arrays, keypoints_from_xy,
+from .types import (ArrayDataBase, DataBase, DMatch, Feature, Frame, KeyPoint, Track, dmatches_from_arrays, keypoints_from_xy,
                     keypoints_to_xy)
 
 # == module constants, as utills.py:17-42 ==
@@ -586,6 +586,22 @@ def find_features_in_consecutive_frames_whole_movie(first_left_ex_cam_mat=M1, mo
         percs.append(100 * int(res.stats[p, 1]) / T)
         rel.append(res.pose[p] if res.ok[p] else None)
     return feats, percs, convert_trans_from_rel_to_global(rel), rel
+
+
+def whole_movie_database(first_left_ex_cam_mat=M1, movie_len=None, seeds=None):
+    """find_features_in_consecutive_frames_whole_movie (:834-873) followed by DataBase(...) (Data.py:42-43) without
+    the Feature objects in between: the supporters' key-point indices go from the device arrays straight into the
+    array-backed track chaining (slam_amd/tracks.py).  Returns an ArrayDataBase, equal accessor by accessor to
+    DataBase(*find_features_in_consecutive_frames_whole_movie(...)) for the same seeds."""
+    n = movie_len if movie_len is not None else min(MOVIE_LEN, len(DETECTIONS)) if hasattr(DETECTIONS, "__len__") else MOVIE_LEN
+    f0, f1 = pipeline.consecutive_pairs(n)
+    res, xy, kp = track_pairs_arrays(np.arange(n), f0, f1, seeds)
+    _check_pairs(res)
+    sup = tracks.supporters_from_shard(res.stats, res.mask, kp)
+    percs = [100 * int(res.stats[p, 1]) / int(res.stats[p, 0]) for p in range(n - 1)]
+    rel = [first_left_ex_cam_mat] + [res.pose[p] if res.ok[p] else None for p in range(n - 1)]
+    glob = convert_trans_from_rel_to_global(rel)
+    return ArrayDataBase(tracks.chain_tracks(sup, xy), sup, xy, percs, glob, rel)
 
 
 def whole_movie(first_left_ex_mat=M1, movie_len=None, seeds=None):

@@ -112,6 +112,22 @@ def test_whole_movie_and_database(golden, movie):
     db = types.DataBase(feats, percs, glob, rel)
     assert db.get_num_frames() == F and db.get_num_tracks() > 100
     assert max(t.get_track_len() for t in db.get_tracks()) >= 3
+    # row N1: the array-backed database built straight from the device index arrays is the same database
+    adb = U.whole_movie_database(U.M1, seeds=seeds)
+    assert isinstance(adb, types.ArrayDataBase) and adb.get_num_tracks() == db.get_num_tracks()
+    assert np.array_equal(adb.get_table().track_len(), [t.get_track_len() for t in db.get_tracks()])
+    for fo, fa in zip(db.get_frames(), adb.get_frames()):
+        assert np.array_equal(fo.get_tracks_ids(), fa.get_tracks_ids())
+        assert np.array_equal(fo.get_ex_cam_mat(), fa.get_ex_cam_mat())
+    for tid in (0, db.get_num_tracks() // 2, db.get_num_tracks() - 1):
+        to, ta = db.get_tracks()[tid], adb.get_tracks()[tid]
+        assert np.array_equal(to.get_frames_ids(), ta.get_frames_ids())
+        assert to.get_left_locations_in_all_frames() == ta.get_left_locations_in_all_frames()
+        assert to.get_right_locations_in_all_frames() == ta.get_right_locations_in_all_frames()
+    assert adb.get_inliers_percentage_per_frame() == percs
+    assert np.array_equal(adb.initial_estimate_poses(), db.initial_estimate_poses())
+    pa = adb.get_prev_and_next_frame_features()
+    assert [f.__getstate__() for f in pa[2][1]] == [f.__getstate__() for f in feats[2][1]]
 
 
 def test_find_loop_cand_by_consensus(golden, movie):

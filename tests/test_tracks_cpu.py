@@ -1,0 +1,130 @@
+"""Array-backed track chaining / ArrayDataBase against the object DataBase, which
+tests/test_types_cpu.py holds to vectors recorded from the reference's DataBase.  No GPU."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from slam_amd import tracks
+from slam_amd.types import ArrayDataBase, DataBase, Feature
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+
+
+def _features(kp, xy_f, cols):
+    xl, xr = xy_f[0], xy_f[1]
+    out = np.empty(len(kp), dtype=object)
+    for j in range(len(kp)):
+        l, r = int(kp[j, cols[0]]), int(kp[j, cols[1]])
+        out[j] = Feature(l, r, float(xl[l, 0]), float(xr[r, 0]), float(xl[l, 1]), float(xr[r, 1]))
+    return out
+
+
+def _both(kp_pairs, xy_frames):
+    n = len(kp_pairs) + 1
+    glob = [np.hstack([np.eye(3), np.array([[0.0], [0.0], [-1.0 * f]])]) for f in range(n)]
+    feats = [[_features(kp, xy_frames[i], (0, 1)), _features(kp, xy_frames[i + 1], (2, 3))] for i, kp in enumerate(kp_pairs)]
+    percs = [50.0] * len(kp_pairs)
+    obj = DataBase(feats, percs, glob, glob)
+    arr = ArrayDataBase(tracks.chain_tracks(kp_pairs, xy_frames), kp_pairs, xy_frames, percs, glob, glob)
+    return obj, arr
+
+
+def _assert_same(obj, arr):
+    assert arr.get_num_tracks() == obj.get_num_tracks() and arr.get_num_frames() == obj.get_num_frames()
+    t = arr.get_table()
+    assert np.array_equal(t.track_len(), [x.get_track_len() for x in obj.get_tracks()])
+    if obj.get_num_tracks():
+        assert np.array_equal(t.track_first_frame(), [x.get_first_frame_ind() for x in obj.get_tracks()])
+    for fo, fa in zip(obj.get_frames(), arr.get_frames()):
+        assert np.array_equal(fo.get_tracks_ids(), fa.get_tracks_ids()) and fo.get_tracks_num() == fa.get_tracks_num()
+        assert fa.get_tracks_ids().dtype == fo.get_tracks_ids().dtype
+    for to, ta in zip(obj.get_tracks(), arr.get_tracks()):
+        assert to.get_id() == ta.get_id() and np.array_equal(to.get_frames_ids(), ta.get_frames_ids())
+        assert to.get_left_locations_in_all_frames() == ta.get_left_locations_in_all_frames()
+        assert to.get_right_locations_in_all_frames() == ta.get_right_locations_in_all_frames()
+        assert to.get_last_frame_ind() == ta.get_last_frame_ind()
+        for f in to.get_frames_ids():
+            a, b = to.get_feature_at_frame(f), ta.get_feature_at_frame(f)
+            assert (a.get_left_kpt(), a.get_right_kpt()) == (b.get_left_kpt(), b.get_right_kpt())
+            assert type(b.get_left_kpt()) is int and type(b.get_left_coor()[0]) is float
+    assert np.array_equal(obj.initial_estimate_poses(), arr.initial_estimate_poses())
+
+
+def _golden_pairs():
+    n = len(G["movie_rel"]) - 1
+    kp = [np.hstack([G[f"movie_f0_kp_{i}"], G[f"movie_f1_kp_{i}"]]) for i in range(n)]
+    return kp, [G["movie_xy"][f] for f in range(n + 1)]
+
+
+def test_golden_movie_matches_the_reference_database():
+    kp, xy = _golden_pairs()
+    t = tracks.chain_tracks(kp, xy)
+    assert t.n_tracks == int(G["db_num_tracks"])
+    assert np.array_equal(t.track_len(), G["db_track_len"]) and np.array_equal(t.track_first_frame(), G["db_track_first"])
+    assert np.array_equal(np.diff(t.frame_ptr), G["db_frame_ntracks"])
+    for f in range(t.n_frames):
+        assert np.array_equal(t.frame_tracks[t.frame_ptr[f]:t.frame_ptr[f + 1]], G[f"db_frame_tracks_{f}"])
+    # coordinates carried by the table are the reference's Feature coordinates
+    for i in range(len(kp)):
+        rows = np.nonzero(t.obs_frame == i + 1)[0]
+        got = {(int(a), int(b)): tuple(c) for (a, b), c in zip(t.obs_kp[rows], t.obs_xy[rows])}
+        for (a, b), (xl, yl, xr, yr) in zip(G[f"movie_f1_kp_{i}"], G[f"movie_f1_xy_{i}"]):
+            assert got[(int(a), int(b))] == (xl, xr, yl, yr)
+    obj, arr = _both(kp, xy)
+    _assert_same(obj, arr)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_chains_equal_the_object_database(seed):
+    rng = np.random.default_rng(seed)
+    n_frames, n_kp = 25, 60
+    xy = [rng.random((2, n_kp, 2)).astype(np.float32) * 1000 for _ in range(n_frames)]
+    kp_pairs = []
+    for i in range(n_frames - 1):
+        n = int(rng.integers(0, 40)) if i != 7 else 0                 # one pair without supporters breaks every track
+        l0 = np.sort(rng.choice(n_kp, n, replace=False))
+        l1 = rng.choice(n_kp, n, replace=False)                       # injective, arbitrary order
+        kp_pairs.append(np.stack([l0, rng.integers(0, n_kp, n), l1, rng.integers(0, n_kp, n)], 1).astype(np.int32).reshape(-1, 4))
+    obj, arr = _both(kp_pairs, xy)
+    _assert_same(obj, arr)
+    # the reference's accessors on top
+    lens = arr.get_table().track_len()
+    if len(lens):
+        L = int(lens[0])
+        assert [t.get_id() for t in arr.get_tracks_with_specific_len(L)] == [t.get_id() for t in obj.get_tracks_with_specific_len(L)]
+        assert arr.tracks_median_len(0.5) == obj.tracks_median_len(0.5)
+        random.seed(5); a = obj.get_rand_track(L).get_id()
+        random.seed(5); b = arr.get_rand_track(L).get_id()
+        assert a == b and random.random() == (random.seed(5), obj.get_rand_track(L), random.random())[2]
+        f = 3
+        assert [t.get_id() for t in arr.get_tracks_at_frame(f)] == [t.get_id() for t in obj.get_tracks_at_frame(f)]
+        assert [x.get_id() for x in arr.get_frames_at_track(0)] == [x.get_id() for x in obj.get_frames_at_track(0)]
+        with pytest.raises(ValueError):
+            arr.get_rand_track(10 ** 6)
+    pf_o, pf_a = obj.get_prev_and_next_frame_features(), arr.get_prev_and_next_frame_features()
+    assert len(pf_o) == len(pf_a)
+    for i in (0, 7, len(pf_o) - 1):
+        for side in range(2):
+            assert [x.__getstate__() for x in pf_o[i][side]] == [x.__getstate__() for x in pf_a[i][side]]
+
+
+def test_duplicates_are_refused_not_mischained():
+    xy = [np.zeros((2, 8, 2), np.float32)] * 3
+    dup_first = [np.array([[1, 0, 2, 0], [1, 0, 3, 0]]), np.array([[2, 0, 4, 0]])]
+    dup_second = [np.array([[1, 0, 2, 0], [5, 0, 2, 0]]), np.array([[2, 0, 4, 0]])]
+    for pairs in (dup_first, dup_second):
+        assert not tracks.pairs_are_chainable(pairs)
+        with pytest.raises(ValueError):
+            tracks.chain_tracks(pairs, xy)
+
+
+def test_empty_movie_and_supporters_from_shard():
+    t = tracks.chain_tracks([np.empty((0, 4), np.int32)], [np.zeros((2, 4, 2), np.float32)] * 2)
+    assert t.n_tracks == 0 and t.n_frames == 2 and len(t.frame_tracks) == 0
+    stats = np.array([[3, 2, 0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 2, 0, 0]], np.int32)
+    mask = np.array([[True, False, True, True], [False] * 4])
+    kp = np.arange(2 * 4 * 4).reshape(2, 4, 4)
+    s = tracks.supporters_from_shard(stats, mask, kp)
+    assert np.array_equal(s[0], kp[0, [0, 2]]) and s[1].shape == (0, 4)
