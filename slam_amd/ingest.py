@@ -18,6 +18,8 @@ streams and events only.
 """
 from __future__ import annotations
 
+import threading
+from collections import OrderedDict
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 
@@ -135,6 +137,47 @@ class ShardStager:
     def host_ready(self, k: int) -> None:
         """Blocks until the last upload of slot k has left the pinned buffer, i.e. the workers may overwrite it."""
         self._uploaded[k % self.n_slots].synchronize()
+
+
+class CachedDetections:
+    """Detection source that remembers the last `capacity` frames.
+
+    The reference re-reads both images and re-runs AKAZE for the current frame and for every loop-closure candidate
+    on every call (utils/utills.py:1126 -> :386-396), although consecutive current frames share most candidates.
+    Detection is a deterministic function of the image, so serving a frame from memory changes no result.  Wraps any
+    source with `get(i) -> (pts_l, dsc_l, pts_r, dsc_r)`; least recently used frames are dropped first."""
+
+    def __init__(self, source, capacity: int = 256):
+        if capacity < 1:
+            raise ValueError("capacity must be positive")
+        self.source, self.capacity = source, int(capacity)
+        self._store = OrderedDict()
+        self._lock = threading.Lock()
+        self.hits = self.misses = 0
+
+    def __len__(self):
+        return len(self.source)
+
+    def get(self, i):
+        i = int(i)
+        with self._lock:
+            got = self._store.get(i)
+            if got is not None:
+                self._store.move_to_end(i)
+                self.hits += 1
+                return got
+        got = self.source.get(i)                    # detect outside the lock: workers may miss on different frames
+        with self._lock:
+            self.misses += 1
+            self._store[i] = got
+            self._store.move_to_end(i)
+            while len(self._store) > self.capacity:
+                self._store.popitem(last=False)
+        return got
+
+    def clear(self):
+        with self._lock:
+            self._store.clear()
 
 
 def shard_ranges(n_frames_total: int, frames_per_shard: int):

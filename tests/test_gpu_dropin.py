@@ -137,3 +137,29 @@ def test_find_loop_cand_by_consensus(golden, movie):
     assert tracks[0].get_track_len() == 2 and list(tracks[0].get_frames_ids()) == [4, 5]
     none = U.find_loop_cand_by_consensus([3, 4], [30, 40], 5, threshold=100, seeds=np.array([1, 2]))
     assert none == []                                              # strict '>' (:1141)
+
+
+def test_loop_candidates_through_the_detection_cache(golden, movie):
+    """Row N2: consecutive current frames share candidates; a cached source detects each frame once and changes nothing."""
+    from slam_amd import ingest
+
+    class Counting:
+        def __init__(self, src): self.src, self.calls = src, []
+        def __len__(self): return len(self.src)
+        def get(self, i):
+            self.calls.append(int(i))
+            return self.src.get(i)
+
+    def summary(out):
+        return [(pg, [(list(t.get_frames_ids()), t.get_left_locations_in_all_frames()) for t in trs]) for pg, trs in out]
+
+    want5 = summary(U.find_loop_cand_by_consensus([1, 2], [10, 20], 5, threshold=50, seeds=np.array([1, 2])))
+    want6 = summary(U.find_loop_cand_by_consensus([1, 2], [10, 20], 6, threshold=50, seeds=np.array([3, 4])))
+    counting = Counting(movie)
+    cache = ingest.CachedDetections(counting, capacity=8)
+    U.set_detection_source(cache)
+    got5 = summary(U.find_loop_cand_by_consensus([1, 2], [10, 20], 5, threshold=50, seeds=np.array([1, 2])))
+    got6 = summary(U.find_loop_cand_by_consensus([1, 2], [10, 20], 6, threshold=50, seeds=np.array([3, 4])))
+    assert got5 == want5 and got6 == want6 and len(want5) + len(want6) > 0
+    assert sorted(counting.calls) == [1, 2, 5, 6]           # candidates 1 and 2 were detected once, not twice
+    assert cache.hits == 2 and cache.misses == 4

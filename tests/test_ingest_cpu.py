@@ -68,3 +68,31 @@ def test_fill_slot_matches_the_source_serial_and_threaded():
                 assert np.array_equal(s.desc[j, side, :n, :61], desc[1 + j, side, :n, :61])
                 assert not s.desc[j, side, :, 61:].any() and not s.desc[j, side, n:].any()
                 assert np.array_equal(s.xy[j, side, :n], xy[1 + j, side, :n]) and not s.xy[j, side, n:].any()
+
+
+def test_cached_detections_serves_repeats_from_memory_and_evicts_lru():
+    class Src:
+        def __init__(self): self.calls = []
+        def __len__(self): return 100
+        def get(self, i):
+            self.calls.append(i)
+            return (np.full((2, 2), i, np.float32), np.full((2, 61), i % 256, np.uint8),) * 2
+    src = Src()
+    c = ingest.CachedDetections(src, capacity=3)
+    assert len(c) == 100
+    a = c.get(5); b = c.get(5)
+    assert a is b and src.calls == [5] and (c.hits, c.misses) == (1, 1)
+    for i in (6, 7):                                   # the loop-closure pattern: same candidates, next current frame
+        c.get(i)
+    c.get(5)                                           # refreshes 5
+    c.get(8)                                           # evicts 6, the least recently used
+    assert src.calls == [5, 6, 7, 8]
+    c.get(5); c.get(7); c.get(8)
+    assert src.calls == [5, 6, 7, 8]
+    c.get(6)
+    assert src.calls == [5, 6, 7, 8, 6]
+    assert np.array_equal(c.get(6)[1], src.get(6)[1])  # what is served is what the source returns
+    c.clear(); c.get(8)
+    assert src.calls[-2:] == [6, 8]
+    with pytest.raises(ValueError):
+        ingest.CachedDetections(src, 0)
