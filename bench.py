@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--chunks", type=int, default=2, help="frame-range chunks pipelined over two HIP streams per GPU")
+    ap.add_argument("--taper", type=float, default=1.0, help="each chunk's size relative to the previous one (1 = equal)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the PCIe-inclusive leg (reported beside, never as, value)")
     return ap.parse_args()
 
@@ -85,7 +86,7 @@ def main():
     P = len(f0)
     seeds = 1000 + rank * P + np.arange(P)            # np.random.seed(1000 + pair index)
     cfg = HotPathConfig()
-    trk = pipeline.ShardTracker(F, P, n_max, cfg, n_chunks=args.chunks)
+    trk = pipeline.ShardTracker(F, P, n_max, cfg, n_chunks=args.chunks, taper=args.taper)
 
     from slam_amd import dist as sdist
 

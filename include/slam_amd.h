@@ -194,7 +194,9 @@ typedef struct SlamTrackConfig {
     int32_t pipeline_chunks; /* > 1: split the pair list into this many contiguous blocks and pipeline them over two
                                 internal streams (RANSAC rounds of one block overlap the matching of the next);
                                 needs pairs that are local in time, otherwise the call falls back to one block */
-    int32_t reserved;
+    int32_t pipeline_taper_permille; /* size of each block relative to the previous one, in 1/1000: 0 or 1000 = equal
+                                blocks; e.g. 450 makes every block 0.45 x the one before, so the un-overlapped tail of
+                                the call belongs to a small block.  Results do not depend on it. */
 } SlamTrackConfig;
 
 typedef struct SlamTrackIO {

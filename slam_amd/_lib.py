@@ -29,7 +29,7 @@ class SlamTrackConfig(ctypes.Structure):
     _fields_ = [("K", c_double * 9), ("M1", c_double * 12), ("M2", c_double * 12), ("rec_err", c_double),
                 ("acc", c_double), ("prob", c_double), ("max_iterations", c_double),
                 ("fixed_iterations", ctypes.c_int32), ("max_draws", ctypes.c_int32), ("norm", ctypes.c_int32),
-                ("first_chunk", ctypes.c_int32), ("pipeline_chunks", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("first_chunk", ctypes.c_int32), ("pipeline_chunks", ctypes.c_int32), ("pipeline_taper_permille", ctypes.c_int32)]
 
 
 class SlamTrackIO(ctypes.Structure):

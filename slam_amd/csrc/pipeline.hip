@@ -437,19 +437,40 @@ thread_local hipEvent_t g_base = nullptr;
 struct Chunk { int a, e, lo, hi; };
 
 // contiguous pair blocks; each needs the frames [lo, hi)
-std::vector<Chunk> plan_chunks(const SlamTrackIO *io, int n_chunks) {
-    std::vector<Chunk> out;
-    const int P = io->n_pairs;
+// Pairs per chunk.  taper (permille) = size of every chunk relative to the one before it: 1000 (or 0) = equal chunks;
+// below 1000 the chunks shrink geometrically, so the tail that nothing overlaps (the last chunk's join / RANSAC /
+// refit / host replay) belongs to a small chunk.  Sizes are >= 1 and sum to P.
+std::vector<int> chunk_sizes(int P, int n_chunks, int taper) {
+    std::vector<int> out;
     if (n_chunks <= 1 || P < 2 * n_chunks) return out;
-    const int per = (P + n_chunks - 1) / n_chunks;
-    for (int a = 0; a < P; a += per) {
-        const int e = a + per < P ? a + per : P;
+    const double r = taper > 0 && taper < 1000 ? taper / 1000.0 : 1.0;
+    double total = 0, w = 1;
+    for (int k = 0; k < n_chunks; ++k, w *= r) total += w;
+    int used = 0;
+    w = 1;
+    for (int k = 0; k < n_chunks; ++k, w *= r) {
+        const int left_after = n_chunks - 1 - k;                     // every later chunk still needs one pair
+        int n = k == n_chunks - 1 ? P - used : (int)(P * w / total + 0.5);
+        n = std::max(1, std::min(n, P - used - left_after));
+        out.push_back(n);
+        used += n;
+    }
+    return out;
+}
+
+std::vector<Chunk> plan_chunks(const SlamTrackIO *io, const SlamTrackConfig *cfg) {
+    std::vector<Chunk> out;
+    const std::vector<int> sizes = chunk_sizes(io->n_pairs, cfg->pipeline_chunks, cfg->pipeline_taper_permille);
+    int a = 0;
+    for (int n : sizes) {
+        const int e = a + n;
         int lo = io->n_frames, hi = 0;
         for (int p = a; p < e; ++p) {
             lo = std::min(lo, std::min(io->h_pair_f0[p], io->h_pair_f1[p]));
             hi = std::max(hi, std::max(io->h_pair_f0[p], io->h_pair_f1[p]) + 1);
         }
         out.push_back({a, e, lo, hi});
+        a = e;
     }
     return out;
 }
@@ -464,10 +485,10 @@ size_t lane_bytes(int F, int P, int N, const SlamTrackConfig *cfg, bool host) {
 // worst-case bytes: the whole shard in one lane, or two lanes of consecutive-frame chunks
 size_t workspace_bytes(int F, int P, int N, const SlamTrackConfig *cfg, bool host) {
     size_t need = lane_bytes(F, P, N, cfg, host);
-    const int C = cfg ? cfg->pipeline_chunks : 0;
-    if (C > 1 && P >= 2 * C) {
-        const int per = (P + C - 1) / C;
-        need = std::max(need, 2 * lane_bytes(per + 1, per, N, cfg, host));
+    if (cfg) {
+        int per = 0;
+        for (int n : chunk_sizes(P, cfg->pipeline_chunks, cfg->pipeline_taper_permille)) per = std::max(per, n);
+        if (per) need = std::max(need, 2 * lane_bytes(per + 1, per, N, cfg, host));
     }
     return need;
 }
@@ -525,7 +546,7 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
     sh.norm = cfg->norm ? cfg->norm : SLAM_NORM_HAMMING2;
 
     // ---- plan: the whole shard in one lane on the caller's stream, or chunks pipelined over two side streams ----
-    std::vector<Chunk> chunks = plan_chunks(io, cfg->pipeline_chunks);
+    std::vector<Chunk> chunks = plan_chunks(io, cfg);
     int lane_F = 0, lane_P = 0;
     for (const Chunk &c : chunks) {
         lane_F = std::max(lane_F, c.hi - c.lo);

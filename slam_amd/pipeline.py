@@ -58,7 +58,8 @@ class ShardTracker:
     VALU-bound matching of the next.  Results are identical to n_chunks = 1: every pair's computation is independent
     of which block carries it."""
 
-    def __init__(self, n_frames: int, n_pairs: int, n_max: int, cfg: HotPathConfig | None = None, n_chunks: int = 1):
+    def __init__(self, n_frames: int, n_pairs: int, n_max: int, cfg: HotPathConfig | None = None, n_chunks: int = 1,
+                 taper: float = 1.0):
         self.cfg = cfg or HotPathConfig()
         self.n_frames, self.n_pairs, self.n_max = n_frames, n_pairs, n_max
         if n_max % 64:
@@ -66,6 +67,7 @@ class ShardTracker:
         self.dev = ops.device()
         self._c = _track_config(self.cfg)
         self._c.pipeline_chunks = max(1, int(n_chunks))
+        self._c.pipeline_taper_permille = int(round(1000 * taper))     # each chunk = taper x the previous one
         L = _lib.lib()
         self.d_ws_bytes = L.slam_track_device_workspace_bytes(n_frames, n_pairs, n_max, ctypes.byref(self._c))
         self.h_ws_bytes = L.slam_track_host_workspace_bytes(n_frames, n_pairs, n_max, ctypes.byref(self._c))

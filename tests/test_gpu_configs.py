@@ -177,3 +177,20 @@ def test_degenerate_frames_empty_and_tiny():
         want = orc.track_pair(_frame(desc, xy, count, 0), _frame(desc, xy, count, 1))
     assert np.array_equal(res.mask[0, :st[0, 0]], want["mask"])
     assert np.linalg.norm(res.pose[0] - want["T"]) / np.linalg.norm(want["T"]) <= REL_TOL
+
+
+def test_results_do_not_depend_on_chunk_plan():
+    """pipeline_chunks / pipeline_taper_permille only schedule the work: every plan gives the single-lane result."""
+    F = 60
+    cfg = SynthConfig(n_frames=F, n_features=500, seed=21, ragged=True)
+    desc, xy, count = SynthSequence(cfg).frames(0, F)
+    n_max = cfg.n_max
+    args = (dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)))
+    f0, f1 = consecutive_pairs(F)
+    seeds = 77 + np.arange(F - 1)
+    base = ShardTracker(F, F - 1, n_max).run(*args, f0, f1, seeds)
+    for chunks, taper in ((2, 0.45), (3, 0.5), (4, 0.001), (16, 0.9), (29, 1.0), (30, 0.7)):   # 30 > P/2: falls back to one lane
+        res = ShardTracker(F, F - 1, n_max, n_chunks=chunks, taper=taper).run(*args, f0, f1, seeds)
+        assert np.array_equal(res.pose, base.pose, equal_nan=True) and np.array_equal(res.mask, base.mask), (chunks, taper)
+        assert np.array_equal(res.stats[:, :6], base.stats[:, :6]), (chunks, taper)
+        assert np.array_equal(res.tracked_kp.cpu().numpy(), base.tracked_kp.cpu().numpy()), (chunks, taper)
