@@ -78,6 +78,64 @@ def test_knn2_bit_exact(norm, shape):
     assert np.array_equal(np.stack([d1, d2], 1), dist_w)
 
 
+@pytest.mark.parametrize("width", [32, 61, 64])
+@pytest.mark.parametrize("norm", [orc.NORM_HAMMING2, orc.NORM_HAMMING])
+def test_descriptor_widths_orb_akaze_full(norm, width):
+    """ORB rows are 32 bytes, AKAZE 61, and a full 64-byte row has no padding at all: same lists as the oracle."""
+    rng = np.random.default_rng(width * 10 + norm)
+    q = rng.integers(0, 256, (700, width), dtype=np.uint8)
+    t = rng.integers(0, 256, (650, width), dtype=np.uint8)
+    t[:200] = q[100:300] ^ (rng.random((200, width)) < 0.03).astype(np.uint8)      # near duplicates: real matches
+    want = c_oracle.match_crosscheck(q, t, norm)
+    got = gpu_crosscheck(q, t, norm)
+    assert len(want[0]) > 150
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+    idx_w, dist_w = c_oracle.knn2(q, t, norm)
+    k1, k2 = ops.match_keys(dev(ops.pad_descriptors(q)), dev(ops.pad_descriptors(t)), norm, _lib.SLAM_MATCH_KNN2)
+    i1, d1 = (x.cpu().numpy() for x in ops.unpack_keys(k1))
+    i2, d2 = (x.cpu().numpy() for x in ops.unpack_keys(k2))
+    assert np.array_equal(np.stack([i1, i2], 1), idx_w) and np.array_equal(np.stack([d1, d2], 1), dist_w)
+
+
+def _ratio_case():
+    """Queries whose two nearest train rows sit at chosen NORM_HAMMING2 distances (d1, d2): the query itself with d1
+    and with d2 two-bit cells changed.  (3, 5), (6, 10), (12, 20), (9, 15), (30, 50) are exact ties of
+    `d1 < 0.6 * d2`; in float64 every such product is the exact integer for all distances up to 244 (checked by
+    enumeration), so ties fail the strict comparison and (2, 5), (29, 50) - one below - pass."""
+    rng = np.random.default_rng(606)
+    plan = [(3, 5), (6, 10), (3, 5), (12, 20), (2, 5), (4, 5), (0, 7), (9, 15), (30, 50), (29, 50), (5, 5)] * 6
+    q = rng.integers(0, 256, (len(plan), 61), dtype=np.uint8)
+    t = []
+    for row, (d1, d2) in zip(q, plan):
+        for d in (d1, d2):
+            r = row.copy()
+            for cell in rng.choice(244, d, replace=False):          # flip the low bit of d distinct 2-bit cells
+                r[cell // 4] ^= 1 << (2 * (cell % 4))
+            t.append(r)
+    t = np.array(t)
+    t = t[rng.permutation(len(t))]
+    return q, t, plan
+
+
+@pytest.mark.parametrize("ratio", [0.6, 0.5, 0.8, 1.0])
+def test_knn_ratio_path_matches_oracle_incl_float_ties(ratio):
+    """Row 2 end to end through the reference-shaped functions (utills.py:92-102, :131-152): the test
+    `d1 < ratio * d2` in float64, strict: exact ties fail, one below the tie passes, as in the reference."""
+    from slam_amd import utills as U
+    q, t, plan = _ratio_case()
+    idx, dist = c_oracle.knn2(q, t, orc.NORM_HAMMING2)
+    assert [tuple(d) for d in dist] == [tuple(p) for p in plan]            # the construction delivers the planned distances
+    wq, wt, wd = orc.knn_ratio_match(q, t, orc.NORM_HAMMING2, ratio)
+    passed, failed = U.significance_test(U.knn_matching(orc.NORM_HAMMING2, q, t), ratio)
+    assert len(passed) + len(failed) == len(q) and 0 < len(passed) < len(q)
+    assert np.array_equal([m.queryIdx for m in passed], wq) and np.array_equal([m.trainIdx for m in passed], wt)
+    assert np.array_equal([m.distance for m in passed], wd)
+    if ratio == 0.6:
+        got = {m.queryIdx for m in passed}
+        assert all((i in got) == (p in ((2, 5), (0, 7), (29, 50))) for i, p in enumerate(plan))
+
+
 def _small_sequence(n_frames=5, n_features=300, seed=3):
     cfg = SynthConfig(n_frames=40, n_features=n_features, seed=seed, spawn_per_frame=40, ragged=13)
     seq = SynthSequence(cfg)
