@@ -128,19 +128,35 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
         P.t[i] = pose0[(size_t)seg * 12 + i * 4 + 3];
     }
 
+    // Both passes walk the points four wave-steps (256 points) at a time with the loads of all four issued before
+    // the arithmetic: one wave per pair is latency bound, and this exposes one memory round trip where there were
+    // four.  Every lane still adds its points in ascending order, so the sums are the bits they were before.
+    constexpr int UN = 4;
     auto cost_of = [&](const Pose &Q) {
         double c = 0;
-        for (int base = 0; base < n; base += 64) {
-            const int i = base + lane;
-            if (i < n && ((mw[i >> 6] >> (i & 63)) & 1ull)) {
-                const double x = Xs[i * 3], y = Xs[i * 3 + 1], z = Xs[i * 3 + 2];
-                const double xc = Q.R[0][0] * x + Q.R[0][1] * y + Q.R[0][2] * z + Q.t[0];
-                const double yc = Q.R[1][0] * x + Q.R[1][1] * y + Q.R[1][2] * z + Q.t[1];
-                const double zc = Q.R[2][0] * x + Q.R[2][1] * y + Q.R[2][2] * z + Q.t[2];
-                const XY4 o = obs[i];
-                const double ru = fx * xc / zc + cx - (double)o.x, rv = fy * yc / zc + cy - (double)o.y;
-                c += ru * ru + rv * rv;
+        for (int base = 0; base < n; base += 64 * UN) {
+            double px[UN], py[UN], pz[UN], ou[UN], ov[UN];
+            bool ok[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = base + u * 64 + lane;
+                ok[u] = i < n && ((mw[i >> 6] >> (i & 63)) & 1ull);
+                if (ok[u]) {
+                    px[u] = Xs[i * 3], py[u] = Xs[i * 3 + 1], pz[u] = Xs[i * 3 + 2];
+                    const XY4 o = obs[i];
+                    ou[u] = (double)o.x, ov[u] = (double)o.y;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (ok[u]) {
+                    const double x = px[u], y = py[u], z = pz[u];
+                    const double xc = Q.R[0][0] * x + Q.R[0][1] * y + Q.R[0][2] * z + Q.t[0];
+                    const double yc = Q.R[1][0] * x + Q.R[1][1] * y + Q.R[1][2] * z + Q.t[1];
+                    const double zc = Q.R[2][0] * x + Q.R[2][1] * y + Q.R[2][2] * z + Q.t[2];
+                    const double ru = fx * xc / zc + cx - ou[u], rv = fy * yc / zc + cy - ov[u];
+                    c += ru * ru + rv * rv;
+                }
         }
         return wave_sum(c);
     };
@@ -156,29 +172,41 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
         for (int k = 0; k < 21; ++k) H[k] = 0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) g[k] = 0;
-        for (int base = 0; base < n; base += 64) {
-            const int i = base + lane;
-            if (i < n && ((mw[i >> 6] >> (i & 63)) & 1ull)) {
-                const double x = Xs[i * 3], y = Xs[i * 3 + 1], z = Xs[i * 3 + 2];
-                const double xc = P.R[0][0] * x + P.R[0][1] * y + P.R[0][2] * z + P.t[0];
-                const double yc = P.R[1][0] * x + P.R[1][1] * y + P.R[1][2] * z + P.t[1];
-                const double zc = P.R[2][0] * x + P.R[2][1] * y + P.R[2][2] * z + P.t[2];
-                const double iz = 1.0 / zc;
-                const XY4 o = obs[i];
-                const double ru = fx * xc * iz + cx - (double)o.x, rv = fy * yc * iz + cy - (double)o.y;
-                // d(u,v)/dXc
-                const double ux = fx * iz, uz = -fx * xc * iz * iz, vy = fy * iz, vz = -fy * yc * iz * iz;
-                // dXc/d(omega) = -[Xc]x, dXc/d(upsilon) = I
-                const double Ju[6] = {uz * yc, ux * zc - uz * xc, -ux * yc, ux, 0.0, uz};
-                const double Jv[6] = {-vy * zc + vz * yc, -vz * xc, vy * xc, 0.0, vy, vz};
-                int k = 0;
+        for (int base = 0; base < n; base += 64 * UN) {
+            double px[UN], py[UN], pz[UN], ou[UN], ov[UN];
+            bool ok[UN];
 #pragma unroll
-                for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                    for (int b = a; b < 6; ++b) H[k++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
-                    g[a] += Ju[a] * ru + Jv[a] * rv;
+            for (int u = 0; u < UN; ++u) {
+                const int i = base + u * 64 + lane;
+                ok[u] = i < n && ((mw[i >> 6] >> (i & 63)) & 1ull);
+                if (ok[u]) {
+                    px[u] = Xs[i * 3], py[u] = Xs[i * 3 + 1], pz[u] = Xs[i * 3 + 2];
+                    const XY4 o = obs[i];
+                    ou[u] = (double)o.x, ov[u] = (double)o.y;
                 }
             }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (ok[u]) {
+                    const double x = px[u], y = py[u], z = pz[u];
+                    const double xc = P.R[0][0] * x + P.R[0][1] * y + P.R[0][2] * z + P.t[0];
+                    const double yc = P.R[1][0] * x + P.R[1][1] * y + P.R[1][2] * z + P.t[1];
+                    const double zc = P.R[2][0] * x + P.R[2][1] * y + P.R[2][2] * z + P.t[2];
+                    const double iz = 1.0 / zc;
+                    const double ru = fx * xc * iz + cx - ou[u], rv = fy * yc * iz + cy - ov[u];
+                    // d(u,v)/dXc
+                    const double ux = fx * iz, uz = -fx * xc * iz * iz, vy = fy * iz, vz = -fy * yc * iz * iz;
+                    // dXc/d(omega) = -[Xc]x, dXc/d(upsilon) = I
+                    const double Ju[6] = {uz * yc, ux * zc - uz * xc, -ux * yc, ux, 0.0, uz};
+                    const double Jv[6] = {-vy * zc + vz * yc, -vz * xc, vy * xc, 0.0, vy, vz};
+                    int k = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                        for (int b = a; b < 6; ++b) H[k++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+                        g[a] += Ju[a] * ru + Jv[a] * rv;
+                    }
+                }
         }
 #pragma unroll
         for (int k = 0; k < 21; ++k) H[k] = wave_sum(H[k]);
