@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--chunks", type=int, default=2, help="frame-range chunks pipelined over two HIP streams per GPU")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): every rank owns its own --frames range of a longer drive; strong: the one "
+                         "--frames sequence is block-partitioned over the ranks (BASELINE configs[2] read literally)")
     ap.add_argument("--taper", type=float, default=1.0, help="each chunk's size relative to the previous one (1 = equal)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the PCIe-inclusive leg (reported beside, never as, value)")
     return ap.parse_args()
@@ -72,33 +75,43 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     # ---- synthetic detections of this rank's frame range (outside the timed region) ----
-    F = args.frames
-    scfg = SynthConfig(n_frames=F, n_features=args.features, seed=args.seed + 7919 * rank)
+    from slam_amd import dist as sdist
+    F_total = args.frames
+    if args.scaling == "strong":
+        # one movie for the whole job; rank r holds the frames of its block of pairs plus one halo frame
+        pa, pb, fa, fb = sdist.shard_frames(F_total, rank, world)
+        scfg = SynthConfig(n_frames=F_total, n_features=args.features, seed=args.seed)
+        pairs_total, first_pair = F_total - 1, pa
+    else:
+        fa, fb = 0, F_total
+        scfg = SynthConfig(n_frames=F_total, n_features=args.features, seed=args.seed + 7919 * rank)
+        pairs_total, first_pair = world * (F_total - 1), rank * (F_total - 1)
     seq = SynthSequence(scfg)
     t0 = time.time()
-    desc, xy, count = seq.frames(0, F)
+    desc, xy, count = seq.frames(fa, fb)
     gen_s = time.time() - t0
+    F = fb - fa
     n_max = scfg.n_max
     d_desc = torch.from_numpy(desc.reshape(2 * F, n_max, 64)).cuda()
     d_xy = torch.from_numpy(xy.reshape(2 * F, n_max, 2)).cuda()
     d_count = torch.from_numpy(count.reshape(2 * F)).cuda()
     f0, f1 = pipeline.consecutive_pairs(F)
     P = len(f0)
-    seeds = 1000 + rank * P + np.arange(P)            # np.random.seed(1000 + pair index)
+    seeds = 1000 + first_pair + np.arange(P)          # np.random.seed(1000 + pair index)
     cfg = HotPathConfig()
     trk = pipeline.ShardTracker(F, P, n_max, cfg, n_chunks=args.chunks, taper=args.taper)
 
-    from slam_amd import dist as sdist
+    n_compose = F_total - 1                           # rank 0 composes the first movie's trajectory
 
     def step():
         res = trk.run(d_desc, d_xy, d_count, f0, f1, seeds, unpack_mask=False)
         # the one exchange of the path: relative poses + counters to every rank (RCCL all-gather over xGMI)
-        rel_all, _ = sdist.gather_shard_results(res.pose, res.stats, world * P)
+        rel_all, _ = sdist.gather_shard_results(res.pose, res.stats, pairs_total)
         glob = None
         if rank == 0:
             # host-side composition (utils/utills.py:749-757); pairs with no pose keep the previous camera
             rel = np.where(np.isfinite(rel_all).all(axis=(1, 2), keepdims=True), rel_all, np.eye(3, 4)[None])
-            glob = pipeline.compose_global(np.concatenate([np.eye(3, 4)[None], rel[:P]]))
+            glob = pipeline.compose_global(np.concatenate([np.eye(3, 4)[None], rel[:n_compose]]))
         return res, glob
 
     def fence():
@@ -124,7 +137,7 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * P * args.steps / elapsed
+        value = pairs_total * args.steps / elapsed
         # ---- roofline of the dominant kernel (all-pairs matcher), from HIP events on the launch stream ----
         cnt = count.astype(np.int64)
         pairs_stereo = int((cnt[:, 0] * cnt[:, 1]).sum())
@@ -153,14 +166,16 @@ def main():
         # trajectory quality against the generator's ground truth (slam_amd/trajectory.py: the reference's
         # between()/camera-centre series condensed into ATE / RPE), outside the timed region
         from slam_amd import trajectory
-        traj = trajectory.summary(glob, np.array([seq.gt_global(i) for i in range(F)]))
+        traj = trajectory.summary(glob, np.array([seq.gt_global(i) for i in range(F_total)]))
         out = {
             "metric": "frame-pairs/sec (match+triangulate+PnP-RANSAC)", "value": round(value, 2), "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 popcount + f64",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32 popcount + f64",
             "data": "synthetic",
-            "config": {"workload": f"synthetic KITTI-shaped stereo, {F} frames x {args.features} features/image per GPU "
-                                   f"(BASELINE configs[1]); {P} frame pairs per GPU per step",
+            "config": {"workload": (f"synthetic KITTI-shaped stereo, {F_total} frames x {args.features} features/image per GPU "
+                                    f"(BASELINE configs[1]); {F_total - 1} frame pairs per GPU per step") if args.scaling == "weak"
+                       else (f"synthetic KITTI-shaped stereo, ONE {F_total}-frame sequence x {args.features} features/image "
+                             f"block-partitioned over {world} GPU(s) (BASELINE configs[2]); {pairs_total} frame pairs per step"),
                        "descriptor_bytes": 61, "norm": "NORM_HAMMING2", "match": "cross-check brute force",
                        "ransac": "adaptive (prob 0.9999, cap 1000), seeds 1000+pair", "parallelism": f"frame-range x{world}"},
             "roofline": roofline,

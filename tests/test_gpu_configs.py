@@ -194,3 +194,30 @@ def test_results_do_not_depend_on_chunk_plan():
         assert np.array_equal(res.pose, base.pose, equal_nan=True) and np.array_equal(res.mask, base.mask), (chunks, taper)
         assert np.array_equal(res.stats[:, :6], base.stats[:, :6]), (chunks, taper)
         assert np.array_equal(res.tracked_kp.cpu().numpy(), base.tracked_kp.cpu().numpy()), (chunks, taper)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_frame_range_shards_reproduce_the_whole_movie(world):
+    """BASELINE configs[2]: the ranks' blocks (slam_amd.dist.shard_frames: pairs [a, b) + one halo frame), run one
+    after the other on this GPU with the global pair index as seed, concatenate to exactly the single-GPU result."""
+    from slam_amd import dist as sdist
+    F = 45
+    cfg = SynthConfig(n_frames=F, n_features=400, seed=8, ragged=True)
+    desc, xy, count = SynthSequence(cfg).frames(0, F)
+    n_max = cfg.n_max
+    f0, f1 = consecutive_pairs(F)
+    whole = ShardTracker(F, F - 1, n_max).run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)),
+                                              dev(count.reshape(2 * F)), f0, f1, 1000 + np.arange(F - 1))
+    pose, stats, mask, covered = [], [], [], []
+    for rank in range(world):
+        a, b, fa, fb = sdist.shard_frames(F, rank, world)
+        if b == a:
+            continue
+        n = fb - fa
+        g0, g1 = consecutive_pairs(n)
+        r = ShardTracker(n, n - 1, n_max, n_chunks=2).run(dev(desc[fa:fb].reshape(2 * n, n_max, 64)), dev(xy[fa:fb].reshape(2 * n, n_max, 2)),
+                                                        dev(count[fa:fb].reshape(2 * n)), g0, g1, 1000 + a + np.arange(b - a))
+        pose.append(r.pose); stats.append(r.stats); mask.append(r.mask); covered += list(range(a, b))
+    assert covered == list(range(F - 1))
+    assert np.array_equal(np.concatenate(pose), whole.pose) and np.array_equal(np.concatenate(mask), whole.mask)
+    assert np.array_equal(np.concatenate(stats)[:, :6], whole.stats[:, :6])
