@@ -26,7 +26,8 @@ extern "C" int slam_match_hamming_batched(const uint8_t *, const int32_t *, int,
 
 namespace {
 
-constexpr long HYP_BUDGET = 1 << 18;       // hypotheses per sub-batch of a later RANSAC round
+constexpr long HYP_BUDGET = 1 << 20;       // hypotheses per sub-batch of a later RANSAC round (pose buffer: 100 MB)
+constexpr int ROUND_QUANTUM = 64;          // later-round draw counts are multiples of this
 constexpr int WORDS_PER_DRAW = 16;         // raw words provisioned per draw (4 indices, acceptance >= 1/2, 2x margin)
 
 struct Carver {
@@ -72,8 +73,7 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     const size_t Fs = F, Ps = P, N = n_max;
     b.D0 = first_chunk(cfg);
     b.W0 = b.D0 * WORDS_PER_DRAW;
-    b.RB = (int)(HYP_BUDGET / ((long)b.D0 * 8));
-    if (b.RB < 1) b.RB = 1;
+    b.RB = (int)(HYP_BUDGET / ROUND_QUANTUM);
     b.stereo_key = d.take<uint32_t>((Fs + Ps) * N);   // one key array: F stereo problems, then P temporal ones
     b.temporal_key = b.stereo_key ? b.stereo_key + Fs * N : nullptr;
     b.prob_q = d.take<int32_t>(Fs + Ps);
@@ -302,22 +302,31 @@ struct Lane {
 
         // ---- later rounds for the pairs whose loop wanted more draws than were evaluated ----
         // The host now knows every pair's point count, so it draws the sample indices itself (same stream, restarted
-        // from the pair's seed) and uploads only the new range [draws consumed so far, + n_eval).
-        long n_eval_l = (long)D0 * 8;
+        // from the pair's seed) and uploads only the new range [draws consumed so far, + n_eval).  Pairs are sorted by
+        // how many draws their loop still asks for (RansacReplay::draws_hint) and cut into sub-batches of at most
+        // HYP_BUDGET hypotheses; a sub-batch evaluates what its hungriest pair asks for.  A pair whose estimate grows
+        // afterwards simply stays active for another round.
         int rc;
+        std::vector<std::pair<int, int>> need;
+        std::vector<uint8_t> fin;
         while (!active.empty()) {
-            if (n_eval_l > HYP_BUDGET) n_eval_l = HYP_BUDGET;
-            const int n_eval = (int)n_eval_l;
-            int rows_per_batch = (int)(HYP_BUDGET / n_eval);
-            if (rows_per_batch > b.RB) rows_per_batch = b.RB;
+            t_h0 = now_ms();
+            need.clear();
+            for (int p : active) need.push_back({rs[p].draws_hint(rp), p});
+            std::stable_sort(need.begin(), need.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first > y.first; });
+            host_ms += now_ms() - t_h0;
             std::vector<int> still;
-            for (size_t a0 = 0; a0 < active.size(); a0 += rows_per_batch) {
-                const int rows = (int)std::min<size_t>(rows_per_batch, active.size() - a0);
+            for (size_t a0 = 0; a0 < need.size();) {
+                long ne = ((long)need[a0].first + ROUND_QUANTUM - 1) / ROUND_QUANTUM * ROUND_QUANTUM;
+                if (ne > HYP_BUDGET) ne = HYP_BUDGET;
+                const int n_eval = (int)ne;
+                int rows = (int)std::min<size_t>(need.size() - a0, (size_t)(HYP_BUDGET / n_eval));
+                if (rows > b.RB) rows = b.RB;
                 t_h0 = now_ms();
                 parallel_for(rows, 1, [&](int a, int e) {
                     std::vector<int32_t> tmp;
                     for (int r = a; r < e; ++r) {
-                        const int p = active[a0 + r];
+                        const int p = need[a0 + r].second;
                         const long begin = rs[p].draws, total = (begin + n_eval) * 4;
                         tmp.resize(total);
                         slam_randint_host(seed[p], (uint32_t)b.h_tcount[p], tmp.data(), total);
@@ -325,7 +334,7 @@ struct Lane {
                                     sizeof(int32_t) * (size_t)n_eval * 4);
                     }
                 });
-                for (int r = 0; r < rows; ++r) b.h_seg_of[r] = active[a0 + r];
+                for (int r = 0; r < rows; ++r) b.h_seg_of[r] = need[a0 + r].second;
                 host_ms += now_ms() - t_h0;
                 SLAM_HIP_CHECK(hipMemcpyAsync(b.seg_of, b.h_seg_of, sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
                 SLAM_HIP_CHECK(hipMemcpyAsync(b.sampleR, b.h_sampleR, sizeof(int32_t) * (size_t)rows * n_eval * 4,
@@ -340,15 +349,20 @@ struct Lane {
                 SLAM_HIP_CHECK(hipMemcpyAsync(b.h_cntR, b.cntR, sizeof(int32_t) * (size_t)rows * n_eval, hipMemcpyDeviceToHost, st));
                 SLAM_HIP_CHECK(hipStreamSynchronize(st));
                 t_h0 = now_ms();
-                for (int r = 0; r < rows; ++r) {
-                    const int p = active[a0 + r];
-                    RansacReplay &s = rs[p];
-                    const int before = s.best_draw, begin = s.draws;
-                    s.consume(rp, b.h_tcount[p], b.h_statusR + (size_t)r * n_eval, b.h_cntR + (size_t)r * n_eval, begin,
-                              begin + n_eval);
-                    b.h_best_idxR[r] = s.best_draw != before ? s.best_draw - begin : -1;
-                    if (!s.finished) still.push_back(p);
-                }
+                fin.assign(rows, 0);
+                parallel_for(rows, 16, [&](int a, int e) {
+                    for (int r = a; r < e; ++r) {
+                        const int p = need[a0 + r].second;
+                        RansacReplay &s = rs[p];
+                        const int before = s.best_draw, begin = s.draws;
+                        s.consume(rp, b.h_tcount[p], b.h_statusR + (size_t)r * n_eval, b.h_cntR + (size_t)r * n_eval, begin,
+                                  begin + n_eval);
+                        b.h_best_idxR[r] = s.best_draw != before ? s.best_draw - begin : -1;
+                        fin[r] = s.finished;
+                    }
+                });
+                for (int r = 0; r < rows; ++r)
+                    if (!fin[r]) still.push_back(need[a0 + r].second);
                 host_ms += now_ms() - t_h0;
                 SLAM_HIP_CHECK(hipMemcpyAsync(b.best_idxR, b.h_best_idxR, sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
                 hipLaunchKernelGGL(gather_best_kernel, dim3(slam_div_up((long)rows * 12, 256)), dim3(256), 0, st, b.poseR,
@@ -356,9 +370,10 @@ struct Lane {
                 SLAM_HIP_CHECK(hipGetLastError());
                 // the next sub-batch reuses the host staging buffers: drain before overwriting them
                 SLAM_HIP_CHECK(hipStreamSynchronize(st));
+                a0 += rows;
             }
+            std::sort(still.begin(), still.end());
             active.swap(still);
-            n_eval_l *= 8;
         }
         SLAM_HIP_CHECK(hipEventRecord(ev[4], st));
         // ---- 5. supporter mask of the winner (pre-refit, as the reference returns) + refit ----

@@ -105,6 +105,23 @@ bool RansacReplay::wants_more(const RansacParams &p) const {
     return (double)it < est && (double)it < p.max_iterations;
 }
 
+int RansacReplay::draws_hint(const RansacParams &p) const {
+    double rem;
+    if (p.fixed_iterations > 0) {
+        rem = (double)p.fixed_iterations - it;
+    } else {
+        const double est = std::log(1.0 - p.prob) / std::log(1.0 - std::pow(1.0 - outliers_perc, 4.0));
+        rem = (est < p.max_iterations ? est : p.max_iterations) - it;
+    }
+    if (!(rem > 1.0)) rem = 1.0;
+    const double ok_rate = draws > 0 ? (double)it / (double)draws : 1.0;
+    double d = rem / (ok_rate > 0.05 ? ok_rate : 0.05) * 1.1 + 32.0;
+    const double left = (double)p.max_draws - draws;
+    if (d > left) d = left;
+    if (!(d >= 1.0)) d = 1.0;
+    return d > 1e9 ? 1000000000 : (int)d;
+}
+
 void RansacReplay::consume(const RansacParams &p, int n_points, const uint8_t *status, const int32_t *count,
                            int draw_begin, int draw_end) {
     // status/count are indexed by (draw - draw_begin)

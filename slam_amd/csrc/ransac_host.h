@@ -20,6 +20,10 @@ struct RansacReplay {
     bool hit_cap = false;
 
     bool wants_more(const RansacParams &p) const;
+    // draws a later round should evaluate for this pair so that the loop very likely finishes inside it: the iterations
+    // the loop still asks for (its current estimate, capped like the loop itself), scaled by the failed-solve rate seen
+    // so far, plus slack.  Only a batch size: consume() stops where the reference's loop stops, whatever was evaluated.
+    int draws_hint(const RansacParams &p) const;
     void consume(const RansacParams &p, int n_points, const uint8_t *status, const int32_t *count, int draw_begin,
                  int draw_end);
 };
