@@ -417,12 +417,12 @@ struct Lane {
         }
         float ms = 0;
         for (int k = 0; k < 5; ++k) {
-            hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+            SLAM_HIP_CHECK(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
             stage_ms[k] += ms;
         }
         float t0 = 0, t1 = 0;
-        hipEventElapsedTime(&t0, base, ev[0]);
-        hipEventElapsedTime(&t1, base, ev[1]);
+        SLAM_HIP_CHECK(hipEventElapsedTime(&t0, base, ev[0]));
+        SLAM_HIP_CHECK(hipEventElapsedTime(&t1, base, ev[1]));
         match_iv.emplace_back(t0, t1);
         return SLAM_OK;
     }
@@ -625,8 +625,9 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
             }
         }
         if (rc) {
-            hipStreamSynchronize(g_side_stream[0]);
-            hipStreamSynchronize(g_side_stream[1]);
+            // the first error is the one reported; still drain both lanes so no work outlives the call
+            (void)hipStreamSynchronize(g_side_stream[0]);
+            (void)hipStreamSynchronize(g_side_stream[1]);
             return rc;
         }
         n_launch = C;
