@@ -33,6 +33,9 @@ namespace {
 #ifndef SLAM_TILE_B
 #define SLAM_TILE_B 128
 #endif
+#ifndef SLAM_JUNROLL
+#define SLAM_JUNROLL 1
+#endif
 constexpr int ROWS = SLAM_ROWS;    // A rows per lane
 constexpr int BLOCK = SLAM_BLOCK;  // threads per workgroup
 constexpr int TILE_A = ROWS * BLOCK;
@@ -187,10 +190,9 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
         const int jbase = tb * TILE_B;
         const int rows_here = min(TILE_B, nb - jbase);
         const uint4 *t = tile[buf];
-        for (int j = 0; j < rows_here; ++j) {
+        // distances of B row j against this lane's ROWS A rows; true if any of them would enter its list
+        auto dist_row = [&](int j, unsigned (&d)[ROWS]) {
             const uint4 b0 = t[j * 4 + 0], b1 = t[j * 4 + 1], b2 = t[j * 4 + 2], b3 = t[j * 4 + 3];
-            const unsigned jg = (unsigned)(jbase + j);
-            unsigned d[ROWS];
             bool improves = false;
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
@@ -202,22 +204,42 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
                 d[r] = acc;
                 improves |= acc < gate[r];
             }
-            // B rows are scanned in ascending order, so a row enters a lane's list iff its distance is strictly
-            // below the list's worst distance.  The key / min / med3 updates (half-rate instructions) are skipped
-            // for the whole wave when no lane improves, which is the common case after the first few hundred rows.
-            if (__any(improves)) {
+            return improves;
+        };
+        auto insert_row = [&](int j, const unsigned (&d)[ROWS]) {
+            const unsigned jg = (unsigned)(jbase + j);
 #pragma unroll
-                for (int r = 0; r < ROWS; ++r) {
-                    const unsigned key = (d[r] << SLAM_KEY_SHIFT) | jg;
-                    if (TOP2) {
-                        top2_insert(m1[r], m2[r], key);
-                        gate[r] = m2[r] >> SLAM_KEY_SHIFT;
-                    } else {
-                        m1[r] = min(m1[r], key);
-                        gate[r] = m1[r] >> SLAM_KEY_SHIFT;
-                    }
+            for (int r = 0; r < ROWS; ++r) {
+                const unsigned key = (d[r] << SLAM_KEY_SHIFT) | jg;
+                if (TOP2) {
+                    top2_insert(m1[r], m2[r], key);
+                    gate[r] = m2[r] >> SLAM_KEY_SHIFT;
+                } else {
+                    m1[r] = min(m1[r], key);
+                    gate[r] = m1[r] >> SLAM_KEY_SHIFT;
                 }
             }
+        };
+        // B rows are scanned in ascending order, so a row enters a lane's list iff its distance is strictly below
+        // the list's worst distance.  The key / min / med3 updates (half-rate instructions) are skipped for the
+        // whole wave when no lane improves, which is the common case after the first few hundred rows.  JU rows
+        // share one such test (inserting a row that does not improve is a no-op, so testing them together only makes
+        // the rare path slightly less rare); the rows of a group are inserted in ascending order.
+        constexpr int JU = SLAM_JUNROLL;
+        int j = 0;
+        for (; j + JU <= rows_here; j += JU) {
+            unsigned d[JU][ROWS];
+            bool improves = false;
+#pragma unroll
+            for (int u = 0; u < JU; ++u) improves |= dist_row(j + u, d[u]);
+            if (__any(improves)) {
+#pragma unroll
+                for (int u = 0; u < JU; ++u) insert_row(j + u, d[u]);
+            }
+        }
+        for (; j < rows_here; ++j) {
+            unsigned d[ROWS];
+            if (__any(dist_row(j, d))) insert_row(j, d);
         }
         if (more) store_tile(buf ^ 1);
         __syncthreads();
