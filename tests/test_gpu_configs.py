@@ -221,3 +221,35 @@ def test_frame_range_shards_reproduce_the_whole_movie(world):
     assert covered == list(range(F - 1))
     assert np.array_equal(np.concatenate(pose), whole.pose) and np.array_equal(np.concatenate(mask), whole.mask)
     assert np.array_equal(np.concatenate(stats)[:, :6], whole.stats[:, :6])
+
+
+def test_draw_cap_bounds_the_retry_loop():
+    """The reference's `while` loop has no bound on draws (utills.py:498-523); max_draws is this library's bound.  With a
+    budget of 500 iterations and a cap of 100 draws the loop stops at the cap, flags SLAM_PAIR_DRAW_CAP, and returns
+    the best of exactly those draws - the oracle with the same cap agrees."""
+    _fast_oracle()
+    F = 3
+    cfg = SynthConfig(n_frames=F, n_features=500, seed=12)
+    desc, xy, count = SynthSequence(cfg).frames(0, F)
+    n_max = cfg.n_max
+    hp = HotPathConfig(fixed_iterations=500, max_draws=100)
+    f0, f1 = consecutive_pairs(F)
+    seeds = np.array([31, 32])
+    res = ShardTracker(F, F - 1, n_max, hp).run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)),
+                                                dev(count.reshape(2 * F)), f0, f1, seeds)
+    for p in range(F - 1):
+        np.random.seed(int(seeds[p]))
+        st = {}
+        with np.errstate(all="ignore"):
+            want = orc.track_pair(_frame(desc, xy, count, p), _frame(desc, xy, count, p + 1), stats=st,
+                                  fixed_iterations=500, max_draws=100)
+        assert res.stats[p, 5] & _lib.SLAM_PAIR_DRAW_CAP and res.stats[p, 5] & _lib.SLAM_PAIR_OK
+        assert res.stats[p, 3] == 100 == st["draws"] and res.stats[p, 2] == st["iterations"] <= 100
+        assert res.stats[p, 4] == st["best_draw"]
+        n = len(want["kp"])
+        assert np.array_equal(res.mask[p, :n], want["mask"])
+        assert np.linalg.norm(res.pose[p] - want["T"]) / np.linalg.norm(want["T"]) <= REL_TOL
+    # without the cap the same pairs are not flagged
+    res2 = ShardTracker(F, F - 1, n_max, HotPathConfig(fixed_iterations=500)).run(
+        dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)), f0, f1, seeds)
+    assert not (res2.stats[:, 5] & _lib.SLAM_PAIR_DRAW_CAP).any() and (res2.stats[:, 2] == 500).all()
