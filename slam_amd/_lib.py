@@ -17,7 +17,7 @@ SLAM_MATCH_CROSSCHECK = 0
 SLAM_MATCH_KNN2 = 1
 SLAM_KEY_SHIFT = 20
 SLAM_KEY_NONE = 0xFFFFFFFF
-SLAM_E_EMPTY = -4
+SLAM_OK, SLAM_E_INVALID, SLAM_E_WORKSPACE, SLAM_E_HIP, SLAM_E_EMPTY = 0, -1, -2, -3, -4
 
 SLAM_PAIR_OK, SLAM_PAIR_EMPTY, SLAM_PAIR_FEW, SLAM_PAIR_DRAW_CAP = 1, 2, 4, 8
 

@@ -83,3 +83,40 @@ def test_ops_refuse_cpu_tensors():
     import torch
     with pytest.raises(ValueError):
         ops.match_keys(torch.zeros((4, 64), dtype=torch.uint8), torch.zeros((4, 64), dtype=torch.uint8))
+
+
+def test_track_pairs_rejects_bad_arguments_before_touching_the_gpu():
+    """Argument validation of slam_track_pairs runs on the host before any HIP call: error code + message, no compute."""
+    import ctypes
+    L = _lib.lib()
+    cfg = _lib.SlamTrackConfig()
+    io = _lib.SlamTrackIO()
+
+    def call():
+        rc = L.slam_track_pairs(ctypes.byref(cfg), ctypes.byref(io), None)
+        return rc, L.slam_last_error_string().decode()
+
+    assert L.slam_track_pairs(None, None, None) == _lib.SLAM_E_INVALID
+    io.n_frames, io.n_pairs, io.n_max = 4, 3, 100                     # n_max not a multiple of 64
+    rc, msg = call()
+    assert rc == _lib.SLAM_E_INVALID and "multiple of 64" in msg
+    io.n_max = 128                                                    # sizes fine, pointers still null
+    rc, msg = call()
+    assert rc == _lib.SLAM_E_INVALID and "null pointer" in msg
+    io.n_pairs = 0                                                    # nothing to do is not an error
+    assert call()[0] == _lib.SLAM_OK
+    # pointers set to host dummies (never dereferenced on the device: validation fails first)
+    buf = (ctypes.c_int32 * 70000)()
+    addr = ctypes.addressof(buf)
+    for name in ("d_desc", "d_xy", "d_count", "h_pair_f0", "h_pair_f1", "h_pair_seed", "d_tracked_kp", "h_pose", "h_stats",
+                 "h_mask", "d_workspace", "h_workspace"):
+        setattr(io, name, addr)
+    io.n_frames, io.n_pairs = 70001, 70000
+    rc, msg = call()
+    assert rc == _lib.SLAM_E_INVALID and "65535" in msg
+    io.n_frames, io.n_pairs = 4, 3
+    buf[1] = 9                                                        # pair 1 names frame 9 of 4
+    rc, msg = call()
+    assert rc == _lib.SLAM_E_INVALID and "pair 1" in msg and "outside" in msg
+    with pytest.raises(_lib.SlamError):
+        _lib.check(rc)

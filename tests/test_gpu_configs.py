@@ -253,3 +253,24 @@ def test_draw_cap_bounds_the_retry_loop():
     res2 = ShardTracker(F, F - 1, n_max, HotPathConfig(fixed_iterations=500)).run(
         dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)), f0, f1, seeds)
     assert not (res2.stats[:, 5] & _lib.SLAM_PAIR_DRAW_CAP).any() and (res2.stats[:, 2] == 500).all()
+
+
+def test_workspace_too_small_is_an_error_not_a_fault():
+    """slam_track_pairs never allocates: a workspace below slam_track_*_workspace_bytes is SLAM_E_WORKSPACE with the
+    needed sizes in the message, and nothing is launched."""
+    import ctypes
+    F = 4
+    cfg = SynthConfig(n_frames=F, n_features=200, seed=2)
+    desc, xy, count = SynthSequence(cfg).frames(0, F)
+    n_max = cfg.n_max
+    trk = ShardTracker(F, F - 1, n_max)
+    trk.d_ws_bytes //= 2                                  # lie about the size; the buffer itself stays large enough
+    f0, f1 = consecutive_pairs(F)
+    with pytest.raises(_lib.SlamError) as e:
+        trk.run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)), f0, f1,
+                np.arange(F - 1))
+    assert "workspace too small" in str(e.value)
+    torch.cuda.synchronize()
+    good = ShardTracker(F, F - 1, n_max).run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)),
+                                             dev(count.reshape(2 * F)), f0, f1, np.arange(F - 1))
+    assert good.ok.all()                                  # the library is still usable after the refusal
