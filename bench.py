@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): every rank owns its own --frames range of a longer drive; strong: the one "
                          "--frames sequence is block-partitioned over the ranks (BASELINE configs[2] read literally)")
+    ap.add_argument("--first-chunk", type=int, default=0, help="hypotheses evaluated speculatively per pair in RANSAC round 0 (0 = library default)")
     ap.add_argument("--taper", type=float, default=1.0, help="each chunk's size relative to the previous one (1 = equal)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the PCIe-inclusive leg (reported beside, never as, value)")
     return ap.parse_args()
@@ -98,7 +99,7 @@ def main():
     f0, f1 = pipeline.consecutive_pairs(F)
     P = len(f0)
     seeds = 1000 + first_pair + np.arange(P)          # np.random.seed(1000 + pair index)
-    cfg = HotPathConfig()
+    cfg = HotPathConfig(first_chunk=args.first_chunk) if args.first_chunk else HotPathConfig()
     trk = pipeline.ShardTracker(F, P, n_max, cfg, n_chunks=args.chunks, taper=args.taper)
 
     n_compose = F_total - 1                           # rank 0 composes the first movie's trajectory
