@@ -49,17 +49,37 @@ __device__ __forceinline__ void jacobi_onesided(double (&A)[N][N], double (&V)[N
 // steps of two DISJOINT column pairs, (0,1)(2,3), (0,2)(1,3), (0,3)(1,2), so two independent scalar chains
 // (2 square roots, 2 divisions each) are in flight per step, and a converged pair is a rotation by zero rather
 // than a branch.
+// 1/sqrt(x) and 1/x to double accuracy from the hardware estimates (v_rsq_f64 / v_rcp_f64, ~2^-26) and two Newton
+// steps each: ~10 instructions where the library sqrt() and division cost ~25 and ~15 with their range fix-ups.  The
+// arguments here are sums of squares of pixel-scale numbers and 1 + t^2, far from the ranges those fix-ups are for.
+// A rotation angle that is off by an ulp only changes how fast the columns become orthogonal, not where they end up.
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    return y;
+}
+
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+
 __device__ __forceinline__ void jacobi_rot_params(double alpha, double beta, double gamma, double &c, double &s,
                                                   bool &rotated) {
     // converged when |gamma| <= 1e-15 sqrt(alpha beta), tested without the square root.  (At 1e-16 about 1.5 % of
     // DLT matrices keep rotating at rounding level until the sweep cap, and one such lane stalls its whole wave.)
     const bool go = gamma * gamma > 1e-30 * (alpha * beta);
     const double d = beta - alpha;
-    const double den = fabs(d) + sqrt(fma(d, d, 4.0 * gamma * gamma));
-    double t = (2.0 * gamma) / den;
+    const double q = fma(d, d, 4.0 * gamma * gamma);
+    const double den = fabs(d) + q * rsqrt_nr(q);          // q = 0 gives NaN here; then go is false and t is discarded
+    double t = (2.0 * gamma) * rcp_nr(den);
     t = d < 0.0 ? -t : t;
     t = go ? t : 0.0;                      // also absorbs 0/0 for a zero column pair
-    c = 1.0 / sqrt(fma(t, t, 1.0));      // not rsqrt(): the device rsqrt is not accurate to double precision
+    c = rsqrt_nr(fma(t, t, 1.0));
     s = c * t;
     rotated |= go;
 }

@@ -10,6 +10,7 @@
 // (rvec, tvec) parameters.  Same minimiser, hence the 1e-5 relative pose tolerance of the parity tests;
 // OpenCV itself is absent, so this is "parity unpinned" against cv2 and pinned against oracle/slam_oracle.py.
 #include "common.h"
+#include "jacobi.h"   // rcp_nr
 #include "kernels.h"
 
 namespace {
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
                     const double xc = Q.R[0][0] * x + Q.R[0][1] * y + Q.R[0][2] * z + Q.t[0];
                     const double yc = Q.R[1][0] * x + Q.R[1][1] * y + Q.R[1][2] * z + Q.t[1];
                     const double zc = Q.R[2][0] * x + Q.R[2][1] * y + Q.R[2][2] * z + Q.t[2];
-                    const double ru = fx * xc / zc + cx - ou[u], rv = fy * yc / zc + cy - ov[u];
+                    const double iz = rcp_nr(zc);      // refined hardware reciprocal: the minimiser does not depend on the last ulp
+                    const double ru = fx * xc * iz + cx - ou[u], rv = fy * yc * iz + cy - ov[u];
                     c += ru * ru + rv * rv;
                 }
         }
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
                     const double xc = P.R[0][0] * x + P.R[0][1] * y + P.R[0][2] * z + P.t[0];
                     const double yc = P.R[1][0] * x + P.R[1][1] * y + P.R[1][2] * z + P.t[1];
                     const double zc = P.R[2][0] * x + P.R[2][1] * y + P.R[2][2] * z + P.t[2];
-                    const double iz = 1.0 / zc;
+                    const double iz = rcp_nr(zc);
                     const double ru = fx * xc * iz + cx - ou[u], rv = fy * yc * iz + cy - ov[u];
                     // d(u,v)/dXc
                     const double ux = fx * iz, uz = -fx * xc * iz * iz, vy = fy * iz, vz = -fy * yc * iz * iz;
