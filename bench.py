@@ -284,15 +284,17 @@ def cpu_baseline(args, seq, desc, xy, count, seeds, res, trk):
         n0, n1 = count[i]
         return dict(dsc_l=desc[i, 0, :n0, :61], dsc_r=desc[i, 1, :n1, :61], xy_l=xy[i, 0, :n0], xy_r=xy[i, 1, :n1])
 
-    t_total, exact_kp, exact_mask, worst_pose = 0.0, 0, 0, 0.0
+    t_total, exact_kp, exact_mask, exact_it, worst_pose = 0.0, 0, 0, 0, 0.0
     for p in picks:
         a, b = frame(p), frame(p + 1)
         a["stereo"] = orc.stereo_match(a["dsc_l"], a["dsc_r"], a["xy_l"], a["xy_r"])   # carried over from the previous pair
         np.random.seed(int(seeds[p]))
         t0 = time.perf_counter()
+        st = {}
         with np.errstate(all="ignore"):
-            want = orc.track_pair(a, b)
+            want = orc.track_pair(a, b, stats=st)
         t_total += time.perf_counter() - t0
+        exact_it += int(res.stats[p, 2] == st.get("iterations", -1))
         T = len(want["kp"])
         exact_kp += int(res.stats[p, 0] == T and np.array_equal(kp[p, :T], want["kp"]))
         exact_mask += int(np.array_equal(mask[p, :T], want["mask"]))
@@ -303,6 +305,7 @@ def cpu_baseline(args, seq, desc, xy, count, seeds, res, trk):
                       f"cross-check matcher (one new stereo match + one temporal match per pair, as the reference's "
                       f"steady state) + numpy triangulation / AP3P / consensus / LM refit",
             "parity_on_sample": {"tracked_sets_bit_exact": f"{exact_kp}/{n}", "supporter_masks_bit_exact": f"{exact_mask}/{n}",
+                                 "adaptive_iteration_counts_equal": f"{exact_it}/{n}",
                                  "worst_pose_rel_err": float(f"{worst_pose:.3e}")}}
 
 

@@ -1,4 +1,4 @@
-// Consensus scoring: one wavefront per pose hypothesis, 64 points per step, ballot + popcount.
+// Consensus scoring: one wavefront per pose hypothesis (two when only counting), 64 points per step, ballot + popcount.
 //
 // Replaces consensus_match (utils/utills.py:533-545) -> compose_transformations (:659-669),
 // find_supporters_4_frame (:672-695), project (:698-705), check_projection (:708-716) and
@@ -67,57 +67,87 @@ __device__ __forceinline__ int within_fast(const double *P, double x, double y, 
     return q < lo ? 1 : (q > hi ? 0 : -1);
 }
 
-constexpr int SB = 256;   // 4 waves = 4 hypotheses of the same segment per workgroup (shared L1 footprint)
+constexpr int SB = 256;   // 4 waves per workgroup, all on the same segment (shared L1 footprint)
 
-template <typename XY4>
+// One wavefront scores HW hypotheses of one segment: every point (24 B + one observation) is loaded once and tested
+// against the HW pose pairs held in registers, so the L1/L2 traffic per hypothesis drops by HW.  HW = 2 for counting
+// (48 doubles of projection matrices per hypothesis), 1 when a mask row is written.
+template <typename XY4, int HW>
 __global__ __launch_bounds__(SB) void score_kernel(Mat33 K, Mat34 M2, const double *X, const XY4 *xy1,
                                                    const int *count, const int *seg_of, int seg_stride,
                                                    const double *pose, const uint8_t *status, int n_hyp, double thr,
                                                    int *inlier_count, unsigned long long *mask) {
     const int row = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int h = blockIdx.x * (SB / 64) + wave;
-    if (h >= n_hyp) return;
+    const int h0 = (blockIdx.x * (SB / 64) + wave) * HW;
+    if (h0 >= n_hyp) return;
     const int seg = seg_of ? seg_of[row] : row;
     const int n = count[seg];
-    const size_t o = (size_t)row * n_hyp + h;
     const int words = seg_stride / 64;
-    unsigned long long *mrow = mask ? mask + o * words : nullptr;
-    const bool live = status[o] != 0;
 
-    double T[12], Tr[12], Pl[12], Pr[12];
+    double Pl[HW][12], Pr[HW][12];
+    bool live[HW];
+    bool any_live = false;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = pose[o * 12 + i];
-    compose_34(M2.m, T, Tr);
-    gemm_33_34(K.m, T, Pl);
-    gemm_33_34(K.m, Tr, Pr);
+    for (int k = 0; k < HW; ++k) {
+        const int h = h0 + k < n_hyp ? h0 + k : h0;          // a wave past the end re-reads its first hypothesis, unused
+        const size_t o = (size_t)row * n_hyp + h;
+        live[k] = h0 + k < n_hyp && status[o] != 0;
+        any_live |= live[k];
+        double T[12], Tr[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = pose[o * 12 + i];
+        compose_34(M2.m, T, Tr);
+        gemm_33_34(K.m, T, Pl[k]);
+        gemm_33_34(K.m, Tr, Pr[k]);
+    }
 
     const double *Xs = X + (size_t)seg * seg_stride * 3;
     const XY4 *obs = xy1 + (size_t)seg * seg_stride;
     // thr < 0 never passes the exact test: an empty band below zero classifies every finite distance as outside
     const double lo = thr < 0.0 ? -1.0 : thr * thr * (1.0 - 1e-9), hi = thr < 0.0 ? -1.0 : thr * thr * (1.0 + 1e-9);
-    int total = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        bool ok = false;
-        if (live && i < n) {
-            const double x = Xs[i * 3 + 0], y = Xs[i * 3 + 1], z = Xs[i * 3 + 2];
-            const XY4 c = obs[i];
-            const int fl = within_fast(Pl, x, y, z, (double)c.x, (double)c.y, lo, hi);
-            const int fr = within_fast(Pr, x, y, z, (double)c.z, (double)c.w, lo, hi);
-            if (fl == 0 || fr == 0)
-                ok = false;                 // decisively outside in one camera: the AND is false either way
-            else if (fl == 1 && fr == 1)
-                ok = true;
-            else                            // within 1e-9 of the radius (or NaN): the reference's arithmetic, literally
-                ok = within(Pl, x, y, z, (double)c.x, (double)c.y, thr) && within(Pr, x, y, z, (double)c.z, (double)c.w, thr);
+    int total[HW];
+#pragma unroll
+    for (int k = 0; k < HW; ++k) total[k] = 0;
+    unsigned long long *mrow = mask ? mask + ((size_t)row * n_hyp + h0) * words : nullptr;   // HW == 1 when mask != null
+    if (any_live || mrow) {
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            bool ok[HW];
+#pragma unroll
+            for (int k = 0; k < HW; ++k) ok[k] = false;
+            if (any_live && i < n) {
+                const double x = Xs[i * 3 + 0], y = Xs[i * 3 + 1], z = Xs[i * 3 + 2];
+                const XY4 c = obs[i];
+                const double ul = (double)c.x, vl = (double)c.y, ur = (double)c.z, vr = (double)c.w;
+#pragma unroll
+                for (int k = 0; k < HW; ++k) {
+                    const int fl = within_fast(Pl[k], x, y, z, ul, vl, lo, hi);
+                    const int fr = within_fast(Pr[k], x, y, z, ur, vr, lo, hi);
+                    bool in;
+                    if (fl == 0 || fr == 0)
+                        in = false;             // decisively outside in one camera: the AND is false either way
+                    else if (fl == 1 && fr == 1)
+                        in = true;
+                    else                        // within 1e-9 of the radius (or NaN): the reference's arithmetic, literally
+                        in = within(Pl[k], x, y, z, ul, vl, thr) && within(Pr[k], x, y, z, ur, vr, thr);
+                    ok[k] = in && live[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < HW; ++k) {
+                const unsigned long long bal = __ballot(ok[k]);
+                total[k] += __popcll(bal);
+                if (HW == 1 && mrow && lane == 0) mrow[base >> 6] = bal;
+            }
         }
-        const unsigned long long bal = __ballot(ok);
-        total += __popcll(bal);
-        if (mrow && lane == 0) mrow[base >> 6] = bal;
     }
-    if (lane == 0) inlier_count[o] = total;
-    if (mrow) {
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < HW; ++k)
+            if (h0 + k < n_hyp) inlier_count[(size_t)row * n_hyp + h0 + k] = total[k];
+    }
+    if (HW == 1 && mrow) {
         for (int w = (n + 63) / 64 + lane; w < words; w += 64) mrow[w] = 0ull;
     }
 }
@@ -147,14 +177,18 @@ int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const 
     if (n_rows <= 0 || n_hyp <= 0) return SLAM_OK;
     SLAM_REQUIRE(n_rows <= 65535, "slam_score_hypotheses: more than 65535 segments per call");
     SLAM_REQUIRE(!d_mask || seg_stride % 64 == 0, "slam_score_hypotheses: seg_stride must be a multiple of 64 for masks");
-    if (xy_f64)
-        hipLaunchKernelGGL(score_kernel<double4>, dim3(slam_div_up(n_hyp, SB / 64), n_rows), dim3(SB), 0, st, K, M2, d_X,
-                           (const double4 *)d_xy1, d_count, d_seg_of, seg_stride, d_pose, d_status, n_hyp, thr,
-                           d_inlier_count, (unsigned long long *)d_mask);
-    else
-        hipLaunchKernelGGL(score_kernel<float4>, dim3(slam_div_up(n_hyp, SB / 64), n_rows), dim3(SB), 0, st, K, M2, d_X,
-                           (const float4 *)d_xy1, d_count, d_seg_of, seg_stride, d_pose, d_status, n_hyp, thr,
-                           d_inlier_count, (unsigned long long *)d_mask);
+    // counting only: two hypotheses per wavefront; with a mask: one (a mask row per hypothesis)
+    const int hw = d_mask ? 1 : 2;
+    const dim3 grid(slam_div_up(n_hyp, (SB / 64) * hw), n_rows), block(SB);
+#define SLAM_SCORE_LAUNCH(XY, HW)                                                                                          \
+    hipLaunchKernelGGL((score_kernel<XY, HW>), grid, block, 0, st, K, M2, d_X, (const XY *)d_xy1, d_count, d_seg_of,       \
+                       seg_stride, d_pose, d_status, n_hyp, thr, d_inlier_count, (unsigned long long *)d_mask)
+    if (xy_f64) {
+        if (hw == 2) SLAM_SCORE_LAUNCH(double4, 2); else SLAM_SCORE_LAUNCH(double4, 1);
+    } else {
+        if (hw == 2) SLAM_SCORE_LAUNCH(float4, 2); else SLAM_SCORE_LAUNCH(float4, 1);
+    }
+#undef SLAM_SCORE_LAUNCH
     SLAM_HIP_CHECK(hipGetLastError());
     return SLAM_OK;
 }

@@ -1,0 +1,72 @@
+"""How often the whole pipeline agrees with the CPU oracle, pair by pair (development / reporting tool; imports oracle/
+as the checker).  Prints the fraction of pairs with identical tracked sets, supporter masks, iteration counts and
+winning draws, the worst pose deviation, and for the pairs that differ how far the triangulated points are apart.
+
+    python tools/oracle_agreement.py [n_frames] [n_features]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import c_oracle  # noqa: E402
+import slam_oracle as orc  # noqa: E402
+from slam_amd import ops  # noqa: E402
+from slam_amd.pipeline import ShardTracker, consecutive_pairs  # noqa: E402
+from slam_amd.synth import SynthConfig, SynthSequence  # noqa: E402
+
+
+def main():
+    F = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 800
+    orc.bf_match = lambda x, y, norm=7: c_oracle.match_crosscheck_w64(c_oracle.pad64(x), c_oracle.pad64(y), norm)
+    cfg = SynthConfig(n_frames=F, n_features=N, seed=99, ragged=True)
+    desc, xy, count = SynthSequence(cfg).frames(0, F)
+    n_max = cfg.n_max
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    f0, f1 = consecutive_pairs(F)
+    res = ShardTracker(F, F - 1, n_max, n_chunks=2).run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)),
+                                                        dev(count.reshape(2 * F)), f0, f1, 1000 + np.arange(F - 1))
+    kp = res.tracked_kp.cpu().numpy()
+    fr = lambda i: dict(dsc_l=desc[i, 0, :count[i, 0], :61], dsc_r=desc[i, 1, :count[i, 1], :61],
+                        xy_l=xy[i, 0, :count[i, 0]], xy_r=xy[i, 1, :count[i, 1]])
+    same_kp = same_mask = same_it = same_best = 0
+    worst = 0.0
+    notes = []
+    P, Q = orc.K @ orc.M1, orc.K @ orc.M2
+    for p in range(F - 1):
+        np.random.seed(1000 + p)
+        st = {}
+        with np.errstate(all="ignore"):
+            w = orc.track_pair(fr(p), fr(p + 1), stats=st)
+        n = len(w["kp"])
+        ok_kp = res.stats[p, 0] == n and np.array_equal(kp[p, :n], w["kp"])
+        ok_mask = ok_kp and np.array_equal(res.mask[p, :n], w["mask"])
+        same_kp += ok_kp
+        same_mask += ok_mask
+        same_it += res.stats[p, 2] == st["iterations"]
+        same_best += res.stats[p, 4] == st["best_draw"]
+        worst = max(worst, float(np.linalg.norm(res.pose[p] - w["T"]) / np.linalg.norm(w["T"])))
+        if res.stats[p, 2] != st["iterations"] and len(notes) < 6 and ok_kp:
+            k = w["kp"]
+            xl = np.stack([xy[p, 0, k[:, 0]], xy[p, 1, k[:, 1]]], 1).astype(np.float64)      # [n, 2(l/r), 2]
+            Xo = orc.triangulate(P, Q, xl[:, 0], xl[:, 1])
+            Xg = ops.triangulate_f64(P, Q, dev(xl[:, 0]), dev(xl[:, 1])).cpu().numpy()
+            rel = np.linalg.norm(Xg - Xo, axis=1) / np.linalg.norm(Xo, axis=1)
+            j = int(np.argmax(rel))
+            notes.append(f"pair {p}: iterations {int(res.stats[p, 2])} vs oracle {st['iterations']}; triangulated points: "
+                         f"median rel diff {np.median(rel):.2e}, max {rel[j]:.2e} at a point of depth {Xo[j, 2]:.1f} m "
+                         f"(disparity {xl[j, 0, 0] - xl[j, 1, 0]:.3f} px); points beyond 1e-9: {int((rel > 1e-9).sum())} of {n}")
+    n = F - 1
+    print(f"pairs {n}: tracked sets equal {same_kp}, supporter masks equal {same_mask}, iteration counts equal {same_it}, "
+          f"winning draw equal {same_best}, worst relative pose deviation {worst:.3e}")
+    for s in notes:
+        print(s)
+
+
+if __name__ == "__main__":
+    main()
