@@ -128,3 +128,16 @@ def test_empty_movie_and_supporters_from_shard():
     kp = np.arange(2 * 4 * 4).reshape(2, 4, 4)
     s = tracks.supporters_from_shard(stats, mask, kp)
     assert np.array_equal(s[0], kp[0, [0, 2]]) and s[1].shape == (0, 4)
+
+
+def test_array_database_saves_and_loads(tmp_path):
+    """DataBase.save / load (DataBase.py:15-34) on the array-backed database, before and after objects were made."""
+    from slam_amd import types
+    kp, xy = _golden_pairs()
+    obj, arr = _both(kp, xy)
+    _ = arr.get_tracks()[3]                                  # one materialised track in the cache
+    path = str(tmp_path / "db.pkl")
+    types.save(path, arr)
+    back = types.load(path)
+    _assert_same(obj, back)
+    assert np.array_equal(back.get_relative_cam_trans(), arr.get_relative_cam_trans())
