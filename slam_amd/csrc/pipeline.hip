@@ -54,14 +54,16 @@ struct Buffers {
     double *pose0, *best_pose, *refit_pose;
     uint8_t *status0, *best_status, *refit_status;
     uint64_t *mask;
-    int32_t *seg_of, *sampleR, *cntR, *best_idxR;
-    double *poseR;
-    uint8_t *statusR;
+    // later-round sub-batches alternate between two slots, so that the host prepares / replays one while the GPU
+    // evaluates the other
+    int32_t *seg_of[2], *sampleR[2], *cntR[2], *best_idxR[2];
+    double *poseR[2];
+    uint8_t *statusR[2];
     // host (pinned)
     uint32_t *h_words0;
-    int32_t *h_prob, *h_tcount, *h_aux, *h_produced0, *h_cnt0, *h_best_idx, *h_best_cnt, *h_seg_of, *h_sampleR,
-        *h_cntR, *h_best_idxR;
-    uint8_t *h_status0, *h_statusR, *h_refit_status;
+    int32_t *h_prob, *h_tcount, *h_aux, *h_produced0, *h_cnt0, *h_best_idx, *h_best_cnt;
+    int32_t *h_seg_of[2], *h_sampleR[2], *h_cntR[2], *h_best_idxR[2];
+    uint8_t *h_status0, *h_statusR[2], *h_refit_status;
     int D0, W0, RB;
     // temporal keys of a chunk with F frames start right after its F stereo key rows
     uint32_t *temporal_key_at(int F, int N) const { return stereo_key + (size_t)F * N; }
@@ -98,12 +100,14 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     b.mask = d.take<uint64_t>(Ps * (N / 64));
     b.refit_pose = d.take<double>(Ps * 12);
     b.refit_status = d.take<uint8_t>(Ps);
-    b.seg_of = d.take<int32_t>(b.RB);
-    b.sampleR = d.take<int32_t>((size_t)HYP_BUDGET * 4);
-    b.poseR = d.take<double>((size_t)HYP_BUDGET * 12);
-    b.statusR = d.take<uint8_t>(HYP_BUDGET);
-    b.cntR = d.take<int32_t>(HYP_BUDGET);
-    b.best_idxR = d.take<int32_t>(b.RB);
+    for (int k = 0; k < 2; ++k) {
+        b.seg_of[k] = d.take<int32_t>(b.RB);
+        b.sampleR[k] = d.take<int32_t>((size_t)HYP_BUDGET * 4);
+        b.poseR[k] = d.take<double>((size_t)HYP_BUDGET * 12);
+        b.statusR[k] = d.take<uint8_t>(HYP_BUDGET);
+        b.cntR[k] = d.take<int32_t>(HYP_BUDGET);
+        b.best_idxR[k] = d.take<int32_t>(b.RB);
+    }
 
     b.h_words0 = h.take<uint32_t>(Ps * b.W0);
     b.h_prob = h.take<int32_t>(2 * (Fs + Ps));
@@ -115,11 +119,13 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     b.h_best_idx = h.take<int32_t>(Ps);
     b.h_best_cnt = h.take<int32_t>(Ps);
     b.h_refit_status = h.take<uint8_t>(Ps);
-    b.h_seg_of = h.take<int32_t>(b.RB);
-    b.h_sampleR = h.take<int32_t>((size_t)HYP_BUDGET * 4);
-    b.h_statusR = h.take<uint8_t>(HYP_BUDGET);
-    b.h_cntR = h.take<int32_t>(HYP_BUDGET);
-    b.h_best_idxR = h.take<int32_t>(b.RB);
+    for (int k = 0; k < 2; ++k) {
+        b.h_seg_of[k] = h.take<int32_t>(b.RB);
+        b.h_sampleR[k] = h.take<int32_t>((size_t)HYP_BUDGET * 4);
+        b.h_statusR[k] = h.take<uint8_t>(HYP_BUDGET);
+        b.h_cntR[k] = h.take<int32_t>(HYP_BUDGET);
+        b.h_best_idxR[k] = h.take<int32_t>(b.RB);
+    }
 }
 
 // best_idx[row] >= 0: copy pose/status of that hypothesis to the segment's "best" slot
@@ -177,6 +183,7 @@ struct Lane {
     Buffers b;
     hipStream_t st = nullptr;
     hipEvent_t ev[6];
+    hipEvent_t evR[2];                               // results of a later-round sub-batch have arrived (per slot)
     bool ev_ready = false;
     // the chunk in flight
     int F = 0, P = 0, pair0 = 0;
@@ -194,6 +201,7 @@ struct Lane {
     int ensure_events() {
         if (!ev_ready) {
             for (auto &e : ev) SLAM_HIP_CHECK(hipEventCreate(&e));
+            for (auto &e : evR) SLAM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ev_ready = true;
         }
         return SLAM_OK;
@@ -306,72 +314,111 @@ struct Lane {
         // how many draws their loop still asks for (RansacReplay::draws_hint) and cut into sub-batches of at most
         // HYP_BUDGET hypotheses; a sub-batch evaluates what its hungriest pair asks for.  A pair whose estimate grows
         // afterwards simply stays active for another round.
+        // Sub-batches are software-pipelined over two buffer slots: while the GPU evaluates sub-batch k the host draws
+        // the indices of k+1 and queues it, then waits for k and replays it, so host and device time overlap.
         int rc;
+        struct Batch { size_t a0; int rows, n_eval; };
         std::vector<std::pair<int, int>> need;
+        std::vector<Batch> batches;
         std::vector<uint8_t> fin;
         while (!active.empty()) {
             t_h0 = now_ms();
             need.clear();
             for (int p : active) need.push_back({rs[p].draws_hint(rp), p});
             std::stable_sort(need.begin(), need.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first > y.first; });
-            host_ms += now_ms() - t_h0;
-            std::vector<int> still;
+            batches.clear();
             for (size_t a0 = 0; a0 < need.size();) {
                 long ne = ((long)need[a0].first + ROUND_QUANTUM - 1) / ROUND_QUANTUM * ROUND_QUANTUM;
                 if (ne > HYP_BUDGET) ne = HYP_BUDGET;
-                const int n_eval = (int)ne;
-                int rows = (int)std::min<size_t>(need.size() - a0, (size_t)(HYP_BUDGET / n_eval));
+                int rows = (int)std::min<size_t>(need.size() - a0, (size_t)(HYP_BUDGET / ne));
                 if (rows > b.RB) rows = b.RB;
-                t_h0 = now_ms();
-                parallel_for(rows, 1, [&](int a, int e) {
+                batches.push_back({a0, rows, (int)ne});
+                a0 += rows;
+            }
+            host_ms += now_ms() - t_h0;
+            std::vector<int> still;
+
+            // host: sample indices of a sub-batch into staging slot s
+            auto draw = [&](const Batch &B, int s) {
+                const double t0 = now_ms();
+                const int n_eval = B.n_eval;
+                parallel_for(B.rows, 1, [&](int a, int e) {
                     std::vector<int32_t> tmp;
                     for (int r = a; r < e; ++r) {
-                        const int p = need[a0 + r].second;
+                        const int p = need[B.a0 + r].second;
                         const long begin = rs[p].draws, total = (begin + n_eval) * 4;
                         tmp.resize(total);
                         slam_randint_host(seed[p], (uint32_t)b.h_tcount[p], tmp.data(), total);
-                        std::memcpy(b.h_sampleR + (size_t)r * n_eval * 4, tmp.data() + begin * 4,
+                        std::memcpy(b.h_sampleR[s] + (size_t)r * n_eval * 4, tmp.data() + begin * 4,
                                     sizeof(int32_t) * (size_t)n_eval * 4);
                     }
                 });
-                for (int r = 0; r < rows; ++r) b.h_seg_of[r] = need[a0 + r].second;
-                host_ms += now_ms() - t_h0;
-                SLAM_HIP_CHECK(hipMemcpyAsync(b.seg_of, b.h_seg_of, sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
-                SLAM_HIP_CHECK(hipMemcpyAsync(b.sampleR, b.h_sampleR, sizeof(int32_t) * (size_t)rows * n_eval * 4,
+                for (int r = 0; r < B.rows; ++r) b.h_seg_of[s][r] = need[B.a0 + r].second;
+                host_ms += now_ms() - t0;
+            };
+            // device: upload, solve, score, download; evR[s] marks the results' arrival
+            auto launch = [&](const Batch &B, int s) -> int {
+                const int rows = B.rows, n_eval = B.n_eval;
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.seg_of[s], b.h_seg_of[s], sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.sampleR[s], b.h_sampleR[s], sizeof(int32_t) * (size_t)rows * n_eval * 4,
                                               hipMemcpyHostToDevice, st));
-                rc = slam_launch_p3p(sh.K, b.X, b.xy1, 0, b.tcount, b.seg_of, rows, N, b.sampleR, n_eval, 0, n_eval, b.poseR,
-                                     b.statusR, st);
-                if (rc) return rc;
-                rc = slam_launch_score(sh.K, sh.M2, b.X, b.xy1, 0, b.tcount, b.seg_of, rows, N, b.poseR, b.statusR, n_eval,
-                                       sh.thr, b.cntR, nullptr, st);
-                if (rc) return rc;
-                SLAM_HIP_CHECK(hipMemcpyAsync(b.h_statusR, b.statusR, (size_t)rows * n_eval, hipMemcpyDeviceToHost, st));
-                SLAM_HIP_CHECK(hipMemcpyAsync(b.h_cntR, b.cntR, sizeof(int32_t) * (size_t)rows * n_eval, hipMemcpyDeviceToHost, st));
-                SLAM_HIP_CHECK(hipStreamSynchronize(st));
-                t_h0 = now_ms();
+                int r2 = slam_launch_p3p(sh.K, b.X, b.xy1, 0, b.tcount, b.seg_of[s], rows, N, b.sampleR[s], n_eval, 0, n_eval,
+                                         b.poseR[s], b.statusR[s], st);
+                if (r2) return r2;
+                r2 = slam_launch_score(sh.K, sh.M2, b.X, b.xy1, 0, b.tcount, b.seg_of[s], rows, N, b.poseR[s], b.statusR[s],
+                                       n_eval, sh.thr, b.cntR[s], nullptr, st);
+                if (r2) return r2;
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.h_statusR[s], b.statusR[s], (size_t)rows * n_eval, hipMemcpyDeviceToHost, st));
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.h_cntR[s], b.cntR[s], sizeof(int32_t) * (size_t)rows * n_eval, hipMemcpyDeviceToHost, st));
+                SLAM_HIP_CHECK(hipEventRecord(evR[s], st));
+                return SLAM_OK;
+            };
+            // host: replay the loop over the downloaded results, then queue the copy of any new winner
+            auto finish = [&](const Batch &B, int s) -> int {
+                const int rows = B.rows, n_eval = B.n_eval;
+                SLAM_HIP_CHECK(hipEventSynchronize(evR[s]));
+                const double t0 = now_ms();
                 fin.assign(rows, 0);
                 parallel_for(rows, 16, [&](int a, int e) {
                     for (int r = a; r < e; ++r) {
-                        const int p = need[a0 + r].second;
-                        RansacReplay &s = rs[p];
-                        const int before = s.best_draw, begin = s.draws;
-                        s.consume(rp, b.h_tcount[p], b.h_statusR + (size_t)r * n_eval, b.h_cntR + (size_t)r * n_eval, begin,
+                        const int p = need[B.a0 + r].second;
+                        RansacReplay &q = rs[p];
+                        const int before = q.best_draw, begin = q.draws;
+                        q.consume(rp, b.h_tcount[p], b.h_statusR[s] + (size_t)r * n_eval, b.h_cntR[s] + (size_t)r * n_eval, begin,
                                   begin + n_eval);
-                        b.h_best_idxR[r] = s.best_draw != before ? s.best_draw - begin : -1;
-                        fin[r] = s.finished;
+                        b.h_best_idxR[s][r] = q.best_draw != before ? q.best_draw - begin : -1;
+                        fin[r] = q.finished;
                     }
                 });
                 for (int r = 0; r < rows; ++r)
-                    if (!fin[r]) still.push_back(need[a0 + r].second);
-                host_ms += now_ms() - t_h0;
-                SLAM_HIP_CHECK(hipMemcpyAsync(b.best_idxR, b.h_best_idxR, sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
-                hipLaunchKernelGGL(gather_best_kernel, dim3(slam_div_up((long)rows * 12, 256)), dim3(256), 0, st, b.poseR,
-                                   b.statusR, b.best_idxR, b.seg_of, rows, n_eval, b.best_pose, b.best_status);
+                    if (!fin[r]) still.push_back(need[B.a0 + r].second);
+                host_ms += now_ms() - t0;
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.best_idxR[s], b.h_best_idxR[s], sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(gather_best_kernel, dim3(slam_div_up((long)rows * 12, 256)), dim3(256), 0, st, b.poseR[s],
+                                   b.statusR[s], b.best_idxR[s], b.seg_of[s], rows, n_eval, b.best_pose, b.best_status);
                 SLAM_HIP_CHECK(hipGetLastError());
-                // the next sub-batch reuses the host staging buffers: drain before overwriting them
-                SLAM_HIP_CHECK(hipStreamSynchronize(st));
-                a0 += rows;
+                return SLAM_OK;
+            };
+
+            const int nb = (int)batches.size();
+            // slot reuse is safe by construction: a slot's host buffers are rewritten only after finish() of the
+            // sub-batch that last used them (its uploads and results are done; its small best-index upload precedes, in
+            // stream order, the launch whose completion finish() of the slot's next user waits for), and its device
+            // buffers only by work queued behind that sub-batch's gather on `st`.
+            draw(batches[0], 0);
+            rc = launch(batches[0], 0);
+            if (rc) return rc;
+            for (int k = 0; k < nb; ++k) {
+                const int s = k & 1;
+                if (k + 1 < nb) {
+                    draw(batches[k + 1], s ^ 1);
+                    rc = launch(batches[k + 1], s ^ 1);
+                    if (rc) return rc;
+                }
+                rc = finish(batches[k], s);
+                if (rc) return rc;
             }
+            SLAM_HIP_CHECK(hipStreamSynchronize(st));      // the next round (or the caller) reuses both slots
             std::sort(still.begin(), still.end());
             active.swap(still);
         }

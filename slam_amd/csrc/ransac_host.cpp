@@ -126,7 +126,21 @@ void RansacReplay::consume(const RansacParams &p, int n_points, const uint8_t *s
                            int draw_begin, int draw_end) {
     // status/count are indexed by (draw - draw_begin)
     while (!finished) {
-        if (!wants_more(p)) {
+        // wants_more(), with the log/pow of the estimate recomputed only when the outlier ratio changed (pairs stuck at
+        // the 0.99 clip run hundreds of iterations on one value)
+        bool more;
+        if (p.fixed_iterations > 0) {
+            more = it < p.fixed_iterations;
+        } else if (outliers_perc == 0.0) {
+            more = false;
+        } else {
+            if (est_for != outliers_perc) {
+                est = std::log(1.0 - p.prob) / std::log(1.0 - std::pow(1.0 - outliers_perc, 4.0));
+                est_for = outliers_perc;
+            }
+            more = (double)it < est && (double)it < p.max_iterations;
+        }
+        if (!more) {
             finished = true;
             break;
         }

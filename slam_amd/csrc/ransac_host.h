@@ -18,6 +18,7 @@ struct RansacReplay {
     int best_draw = -1;
     bool finished = false;
     bool hit_cap = false;
+    double est_for = -1.0, est = 0.0;   // the loop's iteration estimate, cached for the outlier ratio it was computed from
 
     bool wants_more(const RansacParams &p) const;
     // draws a later round should evaluate for this pair so that the loop very likely finishes inside it: the iterations
