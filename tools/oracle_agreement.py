@@ -3,6 +3,8 @@ as the checker).  Prints the fraction of pairs with identical tracked sets, supp
 winning draws, the worst pose deviation, and for the pairs that differ how far the triangulated points are apart.
 
     python tools/oracle_agreement.py [n_frames] [n_features]
+    python tools/oracle_agreement.py --bench [--workers 16]     the bench workload itself (3450 frames x 2000 features,
+                                                                seed 1234), oracle pairs spread over CPU worker processes
 """
 import os
 import sys
@@ -20,7 +22,86 @@ from slam_amd.pipeline import ShardTracker, consecutive_pairs  # noqa: E402
 from slam_amd.synth import SynthConfig, SynthSequence  # noqa: E402
 
 
+_G = {}
+
+
+def _oracle_pair(p):
+    """Worker: the oracle's result for pair p, condensed to what the comparison needs."""
+    desc, xy, count = _G["data"]
+    fr = lambda i: dict(dsc_l=desc[i, 0, :count[i, 0], :61], dsc_r=desc[i, 1, :count[i, 1], :61],
+                        xy_l=xy[i, 0, :count[i, 0]], xy_r=xy[i, 1, :count[i, 1]])
+    np.random.seed(1000 + p)
+    st = {}
+    with np.errstate(all="ignore"):
+        w = orc.track_pair(fr(p), fr(p + 1), stats=st)
+    return p, w["kp"].astype(np.int32), np.packbits(w["mask"]), st["iterations"], st["best_draw"], w["T"]
+
+
+def bench_workload(workers):
+    """Whole bench shard against the oracle.  The oracle pairs run first, in forked CPU workers, before this process
+    touches the GPU (a forked child must not inherit an initialised HIP runtime)."""
+    import json
+    import multiprocessing as mp
+    import time
+    orc.bf_match = lambda x, y, norm=7: c_oracle.match_crosscheck_w64(c_oracle.pad64(x), c_oracle.pad64(y), norm)
+    cfg = SynthConfig(n_frames=3450, n_features=2000, seed=1234)
+    F = cfg.n_frames
+    seq = SynthSequence(cfg)
+    desc, xy, count = seq.frames(0, F)
+    _G["data"] = (desc, xy, count)
+    t0 = time.time()
+    with mp.get_context("fork").Pool(workers) as pool:
+        want = {}
+        for k, r in enumerate(pool.imap_unordered(_oracle_pair, range(F - 1), chunksize=8)):
+            want[r[0]] = r[1:]
+            if k % 500 == 0:
+                print(f"oracle pairs done: {k} ({time.time() - t0:.0f} s)", file=sys.stderr, flush=True)
+    t_cpu = time.time() - t0
+    n_max = cfg.n_max
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    f0, f1 = consecutive_pairs(F)
+    res = ShardTracker(F, F - 1, n_max, n_chunks=2).run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)),
+                                                        dev(count.reshape(2 * F)), f0, f1, 1000 + np.arange(F - 1))
+    kp = res.tracked_kp.cpu().numpy()
+    same = dict(tracked_sets=0, supporter_masks=0, iteration_counts=0, winning_draws=0)
+    pose_dev = np.zeros(F - 1)
+    supp_diff = []
+    for p in range(F - 1):
+        wkp, wmask, wit, wbest, wT = want[p]
+        n = len(wkp)
+        ok_kp = res.stats[p, 0] == n and np.array_equal(kp[p, :n], wkp)
+        ok_mask = ok_kp and np.array_equal(np.packbits(res.mask[p, :n]), wmask)
+        same["tracked_sets"] += int(ok_kp)
+        same["supporter_masks"] += int(ok_mask)
+        same["iteration_counts"] += int(res.stats[p, 2] == wit)
+        same["winning_draws"] += int(res.stats[p, 4] == wbest)
+        if wT is not None:
+            pose_dev[p] = np.linalg.norm(res.pose[p] - wT) / np.linalg.norm(wT)
+        if ok_kp and not ok_mask:
+            supp_diff.append(int(np.unpackbits(np.packbits(res.mask[p, :n]) ^ wmask).sum()))
+    # north_star's third criterion: the trajectory error of the two runs against the generator's ground truth
+    from slam_amd import trajectory
+    from slam_amd.pipeline import compose_global
+    gt = np.array([seq.gt_global(i) for i in range(F)])
+    eye = np.eye(3, 4)[None]
+    fill = lambda rel: np.where(np.isfinite(rel).all(axis=(1, 2), keepdims=True), rel, eye)
+    rel_o = np.array([want[p][4] if want[p][4] is not None else np.full((3, 4), np.nan) for p in range(F - 1)])
+    tr_g = trajectory.summary(compose_global(np.concatenate([eye, fill(res.pose)])), gt)
+    tr_o = trajectory.summary(compose_global(np.concatenate([eye, fill(rel_o)])), gt)
+    ate = {"ate_rmse_m_gpu": tr_g["ate_rmse_m"], "ate_rmse_m_oracle": tr_o["ate_rmse_m"],
+           "ate_rel_diff": abs(tr_g["ate_rmse_m"] - tr_o["ate_rmse_m"]) / tr_o["ate_rmse_m"],
+           "rpe_trans_pct_gpu": tr_g["rpe_trans_pct"], "rpe_trans_pct_oracle": tr_o["rpe_trans_pct"]}
+    out = {"workload": "bench (3450 frames x 2000 features, seed 1234)", "pairs": F - 1, **same, **ate,
+           "pose_rel_dev_median": float(np.median(pose_dev)), "pose_rel_dev_p99": float(np.quantile(pose_dev, 0.99)),
+           "pose_rel_dev_max": float(pose_dev.max()), "pairs_with_pose_dev_above_1e-5": int((pose_dev > 1e-5).sum()),
+           "supporters_differing_where_masks_differ": supp_diff, "oracle_cpu_s": round(t_cpu, 1), "workers": workers}
+    print(json.dumps(out))
+
+
 def main():
+    if "--bench" in sys.argv:
+        w = int(sys.argv[sys.argv.index("--workers") + 1]) if "--workers" in sys.argv else 16
+        return bench_workload(w)
     F = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 800
     orc.bf_match = lambda x, y, norm=7: c_oracle.match_crosscheck_w64(c_oracle.pad64(x), c_oracle.pad64(y), norm)
