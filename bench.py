@@ -243,6 +243,7 @@ def pcie_inclusive(args, desc, xy, count, trk, f0, f1, seeds):
     torch.cuda.synchronize()
     serial_ms = 1e3 * (time.perf_counter() - t0) / n
     st.upload(0)
+    torch.cuda.synchronize()                                              # pipeline filled: steady state of a stream of shards
     t0 = time.perf_counter()
     for k in range(n):                                                    # shard k+1 uploads while shard k is tracked
         st.upload(k + 1)
