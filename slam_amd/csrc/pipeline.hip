@@ -11,7 +11,11 @@
 //   5. supporter mask of the winning hypothesis + LM refit.
 // Host <-> device synchronisation: one per RANSAC round (normally one) and one at the end.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -142,24 +146,96 @@ __global__ void gather_best_kernel(const double *pose, const uint8_t *status, co
     if (k == 0) best_status[seg] = status[o];
 }
 
+// Host worker pool for the per-pair host steps (MT19937 words, loop replay, index drawing).  Persistent: creating
+// and joining 16 threads per call costs several hundred microseconds, which sits on the critical path between a
+// chunk's RANSAC download and its mask / refit launch.  One job at a time (calls from different host threads queue on
+// `gate`); the calling thread works too.
+class HostPool {
+public:
+    static HostPool &get() {
+        static HostPool pool;
+        return pool;
+    }
+    void run(int n_chunks, const std::function<void(int)> &job) {
+        std::lock_guard<std::mutex> serial(gate);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            fn = &job;
+            total = n_chunks;
+            next.store(0);
+            pending = n_chunks;
+            ++generation;
+        }
+        cv_work.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        fn = nullptr;
+    }
+    int workers() const { return (int)threads.size() + 1; }
+
+private:
+    HostPool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        int nt = (int)(hw ? hw : 4);
+        if (nt > 16) nt = 16;
+        for (int t = 1; t < nt; ++t) threads.emplace_back([this] { loop(); });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+            ++generation;
+        }
+        cv_work.notify_all();
+        for (auto &t : threads) t.join();
+    }
+    void work() {
+        for (;;) {
+            const int c = next.fetch_add(1);
+            if (c >= total) return;
+            (*fn)(c);
+            std::lock_guard<std::mutex> lk(m);
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return generation != seen; });
+                seen = generation;
+                if (stop) return;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> threads;
+    std::mutex gate, m;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int)> *fn = nullptr;
+    std::atomic<int> next{0};
+    int total = 0, pending = 0;
+    unsigned long generation = 0;
+    bool stop = false;
+};
+
 template <typename F>
 void parallel_for(int n, int grain, F fn) {
-    unsigned hw = std::thread::hardware_concurrency();
-    int nt = (int)(hw ? hw : 4);
-    if (nt > 16) nt = 16;
+    HostPool &pool = HostPool::get();
+    int nt = pool.workers();
     if (nt > (n + grain - 1) / grain) nt = (n + grain - 1) / grain;
     if (nt <= 1) {
         fn(0, n);
         return;
     }
-    std::vector<std::thread> th;
     const int per = (n + nt - 1) / nt;
-    for (int t = 0; t < nt; ++t) {
-        const int a = t * per, e = a + per < n ? a + per : n;
-        if (a >= e) break;
-        th.emplace_back([=] { fn(a, e); });
-    }
-    for (auto &t : th) t.join();
+    const std::function<void(int)> job = [&](int c) {
+        const int a = c * per, e = a + per < n ? a + per : n;
+        if (a < e) fn(a, e);
+    };
+    pool.run(nt, job);
 }
 
 thread_local double g_timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -662,9 +738,17 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
             L[c].set_chunk(sh, chunks[c].a, chunks[c].e, chunks[c].lo, chunks[c].hi);
             rc = L[c].front(sh);
         }
+        bool mid_done = false;                                   // mid() of chunk c already ran (see below)
         for (int c = 0; c < C && !rc; ++c) {
             Lane &ln = L[c & 1];
-            rc = ln.mid(sh);                                     // the other lane's kernels keep the GPU busy meanwhile
+            if (!mid_done) rc = ln.mid(sh);                      // the other lane's kernels keep the GPU busy meanwhile
+            mid_done = false;
+            if (!rc && c + 2 >= C && c + 1 < C) {
+                // nothing left to queue on this lane: replay the other lane's chunk BEFORE waiting for this one's
+                // refit, so that its mask / refit launch does not sit behind that wait
+                rc = L[(c + 1) & 1].mid(sh);
+                mid_done = true;
+            }
             if (!rc) rc = ln.back(sh);
             if (!rc && c + 2 < C) {
                 ln.set_chunk(sh, chunks[c + 2].a, chunks[c + 2].e, chunks[c + 2].lo, chunks[c + 2].hi);
