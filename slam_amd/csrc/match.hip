@@ -20,6 +20,8 @@
 //   - cross-check (OpenCV batchDistance(crosscheck=true)): A = train rows; the nearest query of
 //     every train row is scattered with atomicMin on key (distance << 20 | train row) into the
 //     query's slot.  min is order independent, so the result is deterministic.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -32,6 +34,23 @@ namespace {
 #endif
 #ifndef SLAM_TILE_B
 #define SLAM_TILE_B 128
+#endif
+#ifdef SLAM_WAVES
+#define SLAM_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SLAM_WAVES, SLAM_WAVES)))
+#else
+#define SLAM_WAVES_ATTR
+#endif
+#ifndef SLAM_PREFETCH
+#define SLAM_PREFETCH 0
+#endif
+#ifndef SLAM_ACC2
+#define SLAM_ACC2 0
+#endif
+#ifndef SLAM_INTERLEAVE
+#define SLAM_INTERLEAVE 8
+#endif
+#ifndef SLAM_ROW_VARIANTS
+#define SLAM_ROW_VARIANTS 1
 #endif
 #ifndef SLAM_JUNROLL
 #define SLAM_JUNROLL 1
@@ -94,6 +113,17 @@ __device__ __forceinline__ unsigned dist_quad(const uint4 &a, const uint4 &b, un
     return acc;
 }
 
+// calls f(integral_constant<int, n>) for the run-time n in [1, N]; n <= 0 does nothing
+template <int N, typename F>
+__device__ __forceinline__ void dispatch_rows(int n, F &f) {
+    if constexpr (N >= 1) {
+        if (n == N)
+            f(std::integral_constant<int, N>{});
+        else
+            dispatch_rows<N - 1>(n, f);
+    }
+}
+
 __device__ __forceinline__ void top2_insert(unsigned &m1, unsigned &m2, unsigned key) {
     // m1 <= m2 invariant; median(m1, m2, key) is the new second best
     unsigned med;
@@ -105,7 +135,7 @@ __device__ __forceinline__ void top2_insert(unsigned &m1, unsigned &m2, unsigned
 // FUSED: cross-check scatter straight from the all-pairs kernel (nsplit == 1).
 // TOP2: keep the second best too (kNN mode); cross-check needs only the nearest row.
 template <bool NORM2, bool FUSED, bool TOP2>
-__global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
+__global__ __launch_bounds__(BLOCK) SLAM_WAVES_ATTR void allpairs_top2_kernel(MatchBatch mb) {
     __shared__ uint4 tile[2][TILE_B * 4];
 
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
@@ -142,10 +172,17 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
     const int tb1 = min(tiles_b, tb0 + tiles_per_split);
 
     const int tid = threadIdx.x;
+    // A wavefront owns 64 * ROWS consecutive rows, slot r = rows [r, r + 1) * 64 of them.  Images hold a few rows less
+    // than the tile grid (1970 of 2048 on the bench data), so the last wavefront of a problem has whole slots without
+    // rows: `nact` (wave-uniform) is the number of slots that have any, and the scan below runs the variant compiled for
+    // that many rows instead of computing distances of zero rows.
+    const int wave_row0 = row0 + (tid >> 6) * (ROWS * 64);
+    auto slot_row = [&](int r) { return wave_row0 + r * 64 + (tid & 63); };
+    const int nact = __builtin_amdgcn_readfirstlane(max(0, min(ROWS, (na - wave_row0 + 63) / 64)));
     uint4 a[ROWS][4];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        const int row = row0 + r * BLOCK + tid;
+        const int row = slot_row(r);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -190,64 +227,133 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
         const int jbase = tb * TILE_B;
         const int rows_here = min(TILE_B, nb - jbase);
         const uint4 *t = tile[buf];
-        // distances of B row j against this lane's ROWS A rows; true if any of them would enter its list
-        auto dist_row = [&](int j, unsigned (&d)[ROWS]) {
-            const uint4 b0 = t[j * 4 + 0], b1 = t[j * 4 + 1], b2 = t[j * 4 + 2], b3 = t[j * 4 + 3];
-            bool improves = false;
+        // NR = active row slots of this wavefront (compile-time in each variant)
+        auto scan_tile = [&](auto nr_tag) {
+            constexpr int NR = decltype(nr_tag)::value;
+            // distances of B row j against this lane's NR A rows; true if any of them would enter its list
+#if SLAM_PREFETCH
+            uint4 nb[4] = {t[0], t[1], t[2], t[3]};         // the B row of the next iteration, read one row ahead
+#endif
+            auto dist_row = [&](int j, unsigned (&d)[ROWS]) {
+#if SLAM_PREFETCH
+                const uint4 b[4] = {nb[0], nb[1], nb[2], nb[3]};
+                const int jn = min(j + 1, TILE_B - 1);
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                unsigned acc = 0;
-                acc = dist_quad<NORM2>(a[r][0], b0, acc);
-                acc = dist_quad<NORM2>(a[r][1], b1, acc);
-                acc = dist_quad<NORM2>(a[r][2], b2, acc);
-                acc = dist_quad<NORM2>(a[r][3], b3, acc);
-                d[r] = acc;
-                improves |= acc < gate[r];
-            }
-            return improves;
-        };
-        auto insert_row = [&](int j, const unsigned (&d)[ROWS]) {
-            const unsigned jg = (unsigned)(jbase + j);
+                for (int c = 0; c < 4; ++c) nb[c] = t[jn * 4 + c];
+                __builtin_amdgcn_sched_barrier(0);
+#else
+                const uint4 b[4] = {t[j * 4 + 0], t[j * 4 + 1], t[j * 4 + 2], t[j * 4 + 3]};
+#endif
+                bool improves = false;
+#if SLAM_INTERLEAVE
+                // The chains (xor -> bitop3 -> bcnt) of NR rows x G words are issued side by side, one step of all of
+                // them at a time: a VALU instruction that depends on one issued a few slots earlier waits, and the
+                // scheduler, left to itself, may emit the rows one after the other.  Measured on the bench shard
+                // (matcher ms): chains one after the other 17.9; 4 side by side 17.2; 8: 16.6; see DESIGN.md.
+                constexpr int G = SLAM_INTERLEAVE;          // words per group (NORM2: a uint4 holds 2, else 4)
+                constexpr int WORDS = NORM2 ? 8 : 16;
+                static_assert(WORDS % G == 0, "group must divide the row");
+                unsigned x[G][ROWS];
+#define SLAM_STEP(expr)                                  \
+    _Pragma("unroll") for (int r = 0; r < NR; ++r) expr; \
+    __builtin_amdgcn_sched_barrier(0);
+                auto w_e = [&](const uint4 &q, int k) { return k ? q.y : q.x; };     // NORM2: E words of a quad
+                auto w_o = [&](const uint4 &q, int k) { return k ? q.w : q.z; };     //        O words
+                auto w_h = [&](const uint4 &q, int k) { return k == 0 ? q.x : k == 1 ? q.y : k == 2 ? q.z : q.w; };
+                SLAM_STEP(d[r] = 0)
+#if SLAM_ACC2
+                unsigned e2[ROWS];
+                SLAM_STEP(e2[r] = 0)
+#endif
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const unsigned key = (d[r] << SLAM_KEY_SHIFT) | jg;
-                if (TOP2) {
-                    top2_insert(m1[r], m2[r], key);
-                    gate[r] = m2[r] >> SLAM_KEY_SHIFT;
-                } else {
-                    m1[r] = min(m1[r], key);
-                    gate[r] = m1[r] >> SLAM_KEY_SHIFT;
+                for (int w0 = 0; w0 < WORDS; w0 += G) {
+                    if (NORM2) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) SLAM_STEP(x[g][r] = w_o(a[r][(w0 + g) / 2], (w0 + g) & 1) ^ w_o(b[(w0 + g) / 2], (w0 + g) & 1))
+#pragma unroll
+                        for (int g = 0; g < G; ++g) SLAM_STEP(x[g][r] = __builtin_amdgcn_bitop3_b32(w_e(a[r][(w0 + g) / 2], (w0 + g) & 1), x[g][r], w_e(b[(w0 + g) / 2], (w0 + g) & 1), 0xde))
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) SLAM_STEP(x[g][r] = w_h(a[r][(w0 + g) / 4], (w0 + g) & 3) ^ w_h(b[(w0 + g) / 4], (w0 + g) & 3))
+                    }
+#if SLAM_ACC2
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        if (g & 1) { SLAM_STEP(e2[r] = bcnt_acc(x[g][r], e2[r])) } else { SLAM_STEP(d[r] = bcnt_acc(x[g][r], d[r])) }
+                    }
+#else
+#pragma unroll
+                    for (int g = 0; g < G; ++g) SLAM_STEP(d[r] = bcnt_acc(x[g][r], d[r]))
+#endif
+                }
+#if SLAM_ACC2
+                SLAM_STEP(d[r] += e2[r])
+#endif
+#undef SLAM_STEP
+#pragma unroll
+                for (int r = 0; r < NR; ++r) improves |= d[r] < gate[r];
+#else
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    unsigned acc = 0;
+                    acc = dist_quad<NORM2>(a[r][0], b[0], acc);
+                    acc = dist_quad<NORM2>(a[r][1], b[1], acc);
+                    acc = dist_quad<NORM2>(a[r][2], b[2], acc);
+                    acc = dist_quad<NORM2>(a[r][3], b[3], acc);
+                    d[r] = acc;
+                    improves |= acc < gate[r];
+                }
+#endif
+                return improves;
+            };
+            auto insert_row = [&](int j, const unsigned (&d)[ROWS]) {
+                const unsigned jg = (unsigned)(jbase + j);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const unsigned key = (d[r] << SLAM_KEY_SHIFT) | jg;
+                    if (TOP2) {
+                        top2_insert(m1[r], m2[r], key);
+                        gate[r] = m2[r] >> SLAM_KEY_SHIFT;
+                    } else {
+                        m1[r] = min(m1[r], key);
+                        gate[r] = m1[r] >> SLAM_KEY_SHIFT;
+                    }
+                }
+            };
+            // B rows are scanned in ascending order, so a row enters a lane's list iff its distance is strictly below
+            // the list's worst distance.  The key / min / med3 updates (half-rate instructions) are skipped for the
+            // whole wave when no lane improves, which is the common case after the first few hundred rows.  JU rows
+            // share one such test (inserting a row that does not improve is a no-op, so testing them together only
+            // makes the rare path slightly less rare); the rows of a group are inserted in ascending order.
+            constexpr int JU = SLAM_JUNROLL;
+            int j = 0;
+            for (; j + JU <= rows_here; j += JU) {
+                unsigned d[JU][ROWS];
+                bool improves = false;
+#pragma unroll
+                for (int u = 0; u < JU; ++u) improves |= dist_row(j + u, d[u]);
+                if (__any(improves)) {
+#pragma unroll
+                    for (int u = 0; u < JU; ++u) insert_row(j + u, d[u]);
                 }
             }
-        };
-        // B rows are scanned in ascending order, so a row enters a lane's list iff its distance is strictly below
-        // the list's worst distance.  The key / min / med3 updates (half-rate instructions) are skipped for the
-        // whole wave when no lane improves, which is the common case after the first few hundred rows.  JU rows
-        // share one such test (inserting a row that does not improve is a no-op, so testing them together only makes
-        // the rare path slightly less rare); the rows of a group are inserted in ascending order.
-        constexpr int JU = SLAM_JUNROLL;
-        int j = 0;
-        for (; j + JU <= rows_here; j += JU) {
-            unsigned d[JU][ROWS];
-            bool improves = false;
-#pragma unroll
-            for (int u = 0; u < JU; ++u) improves |= dist_row(j + u, d[u]);
-            if (__any(improves)) {
-#pragma unroll
-                for (int u = 0; u < JU; ++u) insert_row(j + u, d[u]);
+            for (; j < rows_here; ++j) {
+                unsigned d[ROWS];
+                if (__any(dist_row(j, d))) insert_row(j, d);
             }
-        }
-        for (; j < rows_here; ++j) {
-            unsigned d[ROWS];
-            if (__any(dist_row(j, d))) insert_row(j, d);
-        }
+        };
+#if SLAM_ROW_VARIANTS
+        dispatch_rows<ROWS>(nact, scan_tile);
+#else
+        scan_tile(std::integral_constant<int, ROWS>{});
+#endif
         if (more) store_tile(buf ^ 1);
         __syncthreads();
     }
 
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        const int row = row0 + r * BLOCK + tid;
+        const int row = slot_row(r);
         if (row >= na) continue;
         if (FUSED) {
             // A = train rows, B = query rows: scatter (distance, train row) into the nearest query's slot
