@@ -16,6 +16,10 @@
 //     wins ties because the index is in the key's low bits.  The key/min/med3 updates are half-rate instructions
 //     on gfx950 (tools/valu_peak.hip), so they sit behind a wave-uniform "does any lane improve" test and are
 //     skipped for most B rows.
+//   - a wavefront owns 64 * ROWS consecutive A rows; the last wavefront of an image, whose trailing row slots are
+//     empty, runs a variant compiled for fewer rows.
+//   - the 32 distance chains of a B row (4 rows x 8 words) are issued side by side, one step of all of them at a
+//     time (32 x v_xor, 32 x v_bitop3, 32 x v_bcnt): the order matters by 15 % on this part.
 //   - tile shape (4 rows/lane, 256 threads, 128-row B tiles) chosen by a sweep on the MI355X.
 //   - cross-check (OpenCV batchDistance(crosscheck=true)): A = train rows; the nearest query of
 //     every train row is scattered with atomicMin on key (distance << 20 | train row) into the
@@ -34,17 +38,6 @@ namespace {
 #endif
 #ifndef SLAM_TILE_B
 #define SLAM_TILE_B 128
-#endif
-#ifdef SLAM_WAVES
-#define SLAM_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SLAM_WAVES, SLAM_WAVES)))
-#else
-#define SLAM_WAVES_ATTR
-#endif
-#ifndef SLAM_PREFETCH
-#define SLAM_PREFETCH 0
-#endif
-#ifndef SLAM_ACC2
-#define SLAM_ACC2 0
 #endif
 #ifndef SLAM_INTERLEAVE
 #define SLAM_INTERLEAVE 8
@@ -135,7 +128,7 @@ __device__ __forceinline__ void top2_insert(unsigned &m1, unsigned &m2, unsigned
 // FUSED: cross-check scatter straight from the all-pairs kernel (nsplit == 1).
 // TOP2: keep the second best too (kNN mode); cross-check needs only the nearest row.
 template <bool NORM2, bool FUSED, bool TOP2>
-__global__ __launch_bounds__(BLOCK) SLAM_WAVES_ATTR void allpairs_top2_kernel(MatchBatch mb) {
+__global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
     __shared__ uint4 tile[2][TILE_B * 4];
 
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
@@ -231,19 +224,8 @@ __global__ __launch_bounds__(BLOCK) SLAM_WAVES_ATTR void allpairs_top2_kernel(Ma
         auto scan_tile = [&](auto nr_tag) {
             constexpr int NR = decltype(nr_tag)::value;
             // distances of B row j against this lane's NR A rows; true if any of them would enter its list
-#if SLAM_PREFETCH
-            uint4 nb[4] = {t[0], t[1], t[2], t[3]};         // the B row of the next iteration, read one row ahead
-#endif
             auto dist_row = [&](int j, unsigned (&d)[ROWS]) {
-#if SLAM_PREFETCH
-                const uint4 b[4] = {nb[0], nb[1], nb[2], nb[3]};
-                const int jn = min(j + 1, TILE_B - 1);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) nb[c] = t[jn * 4 + c];
-                __builtin_amdgcn_sched_barrier(0);
-#else
                 const uint4 b[4] = {t[j * 4 + 0], t[j * 4 + 1], t[j * 4 + 2], t[j * 4 + 3]};
-#endif
                 bool improves = false;
 #if SLAM_INTERLEAVE
                 // The chains (xor -> bitop3 -> bcnt) of NR rows x G words are issued side by side, one step of all of
@@ -261,10 +243,6 @@ __global__ __launch_bounds__(BLOCK) SLAM_WAVES_ATTR void allpairs_top2_kernel(Ma
                 auto w_o = [&](const uint4 &q, int k) { return k ? q.w : q.z; };     //        O words
                 auto w_h = [&](const uint4 &q, int k) { return k == 0 ? q.x : k == 1 ? q.y : k == 2 ? q.z : q.w; };
                 SLAM_STEP(d[r] = 0)
-#if SLAM_ACC2
-                unsigned e2[ROWS];
-                SLAM_STEP(e2[r] = 0)
-#endif
 #pragma unroll
                 for (int w0 = 0; w0 < WORDS; w0 += G) {
                     if (NORM2) {
@@ -276,19 +254,9 @@ __global__ __launch_bounds__(BLOCK) SLAM_WAVES_ATTR void allpairs_top2_kernel(Ma
 #pragma unroll
                         for (int g = 0; g < G; ++g) SLAM_STEP(x[g][r] = w_h(a[r][(w0 + g) / 4], (w0 + g) & 3) ^ w_h(b[(w0 + g) / 4], (w0 + g) & 3))
                     }
-#if SLAM_ACC2
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        if (g & 1) { SLAM_STEP(e2[r] = bcnt_acc(x[g][r], e2[r])) } else { SLAM_STEP(d[r] = bcnt_acc(x[g][r], d[r])) }
-                    }
-#else
 #pragma unroll
                     for (int g = 0; g < G; ++g) SLAM_STEP(d[r] = bcnt_acc(x[g][r], d[r]))
-#endif
                 }
-#if SLAM_ACC2
-                SLAM_STEP(d[r] += e2[r])
-#endif
 #undef SLAM_STEP
 #pragma unroll
                 for (int r = 0; r < NR; ++r) improves |= d[r] < gate[r];
