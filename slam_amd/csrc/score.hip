@@ -14,6 +14,8 @@
 //   - the test is sqrt(dx*dx + dy*dy) <= acc**2 (the reference compares the UN-squared distance with acc squared);
 //     no positive-depth test; NaN compares false.
 // Compiled with -ffp-contract=off, so nothing below is fused except the explicit fma() calls.
+#include <cmath>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -67,12 +69,35 @@ __device__ __forceinline__ int within_fast(const double *P, double x, double y, 
     return q < lo ? 1 : (q > hi ? 0 : -1);
 }
 
+// Both cameras at once for a rectified pair (RECT, decided on the host from K and M2, see rectified_rig): with
+// K = [fx 0 cx; 0 fy cy; 0 0 1] and M2 = [I | (tx, 0, 0)] numpy's `M2 @ [T; 0 0 0 1]` returns the rows of T unchanged
+// except element (0, 3), and `K @ .` then gives a right projection matrix that differs from the left one in element
+// (0, 3) only -- bit for bit, because the extra terms are exact zeros and ones.  So hy, hz and the dot product inside hx
+// are the left camera's; only the addend of hx and the observation differ.  Returns the AND of the two classifications:
+// 1 inside both, 0 outside one, -1 undecided (then the caller runs the exact test on the full matrices, which also
+// covers non-finite poses: a NaN anywhere in T makes a left coordinate NaN, hence q NaN, hence -1).
+__device__ __forceinline__ int within_fast_rect(const double *Pl, double pr3, double x, double y, double z, double ul,
+                                                double vl, double ur, double vr, double lo, double hi) {
+    const double sx = fma(z, Pl[2], fma(y, Pl[1], x * Pl[0]));
+    const double hxl = sx + Pl[3], hxr = sx + pr3;
+    const double hy = fma(z, Pl[6], fma(y, Pl[5], x * Pl[4])) + Pl[7];
+    const double hz = fma(z, Pl[10], fma(y, Pl[9], x * Pl[8])) + Pl[11];
+    double r = __builtin_amdgcn_rcp(hz);
+    r = fma(r, fma(-hz, r, 1.0), r);
+    r = fma(r, fma(-hz, r, 1.0), r);
+    const double py = hy * r;
+    const double dxl = hxl * r - ul, dyl = py - vl, dxr = hxr * r - ur, dyr = py - vr;
+    const double ql = fma(dxl, dxl, dyl * dyl), qr = fma(dxr, dxr, dyr * dyr);
+    if (ql > hi || qr > hi) return 0;
+    return (ql < lo && qr < lo) ? 1 : -1;
+}
+
 constexpr int SB = 256;   // 4 waves per workgroup, all on the same segment (shared L1 footprint)
 
 // One wavefront scores HW hypotheses of one segment: every point (24 B + one observation) is loaded once and tested
 // against the HW pose pairs held in registers, so the L1/L2 traffic per hypothesis drops by HW.  HW = 2 for counting
 // (48 doubles of projection matrices per hypothesis), 1 when a mask row is written.
-template <typename XY4, int HW>
+template <typename XY4, int HW, bool RECT>
 __global__ __launch_bounds__(SB) void score_kernel(Mat33 K, Mat34 M2, const double *X, const XY4 *xy1,
                                                    const int *count, const int *seg_of, int seg_stride,
                                                    const double *pose, const uint8_t *status, int n_hyp, double thr,
@@ -122,14 +147,17 @@ __global__ __launch_bounds__(SB) void score_kernel(Mat33 K, Mat34 M2, const doub
                 const double ul = (double)c.x, vl = (double)c.y, ur = (double)c.z, vr = (double)c.w;
 #pragma unroll
                 for (int k = 0; k < HW; ++k) {
-                    const int fl = within_fast(Pl[k], x, y, z, ul, vl, lo, hi);
-                    const int fr = within_fast(Pr[k], x, y, z, ur, vr, lo, hi);
-                    bool in;
-                    if (fl == 0 || fr == 0)
-                        in = false;             // decisively outside in one camera: the AND is false either way
-                    else if (fl == 1 && fr == 1)
-                        in = true;
-                    else                        // within 1e-9 of the radius (or NaN): the reference's arithmetic, literally
+                    int f;
+                    if (RECT) {
+                        f = within_fast_rect(Pl[k], Pr[k][3], x, y, z, ul, vl, ur, vr, lo, hi);
+                    } else {
+                        const int fl = within_fast(Pl[k], x, y, z, ul, vl, lo, hi);
+                        const int fr = within_fast(Pr[k], x, y, z, ur, vr, lo, hi);
+                        // decisively outside in one camera: the AND is false either way
+                        f = (fl == 0 || fr == 0) ? 0 : ((fl == 1 && fr == 1) ? 1 : -1);
+                    }
+                    bool in = f == 1;
+                    if (f < 0)                  // within 1e-9 of the radius (or NaN): the reference's arithmetic, literally
                         in = within(Pl[k], x, y, z, ul, vl, thr) && within(Pr[k], x, y, z, ur, vr, thr);
                     ok[k] = in && live[k];
                 }
@@ -167,6 +195,16 @@ __global__ __launch_bounds__(256) void consensus_f64_kernel(Mat33 K, Mat34 M2, M
     mask[i] = within(Pl, x, y, z, a.x, a.y, thr) && within(Pr, x, y, z, b.x, b.y, thr);
 }
 
+// K = [fx 0 cx; 0 fy cy; 0 0 1] and M2 = [I | (tx, 0, 0)], element for element (the KITTI rig of the reference; any other
+// rig takes the general kernel)
+bool rectified_rig(const Mat33 &K, const Mat34 &M2) {
+    const double *k = K.m, *m = M2.m;
+    return k[1] == 0.0 && k[3] == 0.0 && k[6] == 0.0 && k[7] == 0.0 && k[8] == 1.0 && m[0] == 1.0 && m[1] == 0.0 &&
+           m[2] == 0.0 && m[4] == 0.0 && m[5] == 1.0 && m[6] == 0.0 && m[7] == 0.0 && m[8] == 0.0 && m[9] == 0.0 &&
+           m[10] == 1.0 && m[11] == 0.0 && std::isfinite(k[0]) && std::isfinite(k[2]) && std::isfinite(k[4]) &&
+           std::isfinite(k[5]) && std::isfinite(m[3]);
+}
+
 }  // namespace
 
 int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const void *d_xy1, int xy_f64,
@@ -180,14 +218,20 @@ int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const 
     // counting only: two hypotheses per wavefront; with a mask: one (a mask row per hypothesis)
     const int hw = d_mask ? 1 : 2;
     const dim3 grid(slam_div_up(n_hyp, (SB / 64) * hw), n_rows), block(SB);
-#define SLAM_SCORE_LAUNCH(XY, HW)                                                                                          \
-    hipLaunchKernelGGL((score_kernel<XY, HW>), grid, block, 0, st, K, M2, d_X, (const XY *)d_xy1, d_count, d_seg_of,       \
+    const bool rect = rectified_rig(K, M2);
+#define SLAM_SCORE_LAUNCH(XY, HW, RECT)                                                                                    \
+    hipLaunchKernelGGL((score_kernel<XY, HW, RECT>), grid, block, 0, st, K, M2, d_X, (const XY *)d_xy1, d_count, d_seg_of, \
                        seg_stride, d_pose, d_status, n_hyp, thr, d_inlier_count, (unsigned long long *)d_mask)
+#define SLAM_SCORE_LAUNCH_HW(XY, RECT)                                          \
+    do {                                                                        \
+        if (hw == 2) SLAM_SCORE_LAUNCH(XY, 2, RECT); else SLAM_SCORE_LAUNCH(XY, 1, RECT); \
+    } while (0)
     if (xy_f64) {
-        if (hw == 2) SLAM_SCORE_LAUNCH(double4, 2); else SLAM_SCORE_LAUNCH(double4, 1);
+        if (rect) SLAM_SCORE_LAUNCH_HW(double4, true); else SLAM_SCORE_LAUNCH_HW(double4, false);
     } else {
-        if (hw == 2) SLAM_SCORE_LAUNCH(float4, 2); else SLAM_SCORE_LAUNCH(float4, 1);
+        if (rect) SLAM_SCORE_LAUNCH_HW(float4, true); else SLAM_SCORE_LAUNCH_HW(float4, false);
     }
+#undef SLAM_SCORE_LAUNCH_HW
 #undef SLAM_SCORE_LAUNCH
     SLAM_HIP_CHECK(hipGetLastError());
     return SLAM_OK;

@@ -226,7 +226,17 @@ def test_consensus_masks_bit_exact_against_reference_golden(golden):
     assert cnt[H] == 0 and cnt[H + 1] == 0 and not mask[H:].any()
 
 
-def test_scoring_bit_exact_large_random():
+def _general_rig():
+    """A calibration with skew and a right camera that is rotated and shifted in all axes: none of the structure the
+    rectified-rig scoring kernel relies on."""
+    Kg = np.array([[700.0, 1.5, 600.0], [0.0, 710.0, 180.0], [0.0, 0.0, 1.0]])
+    M2g = np.hstack([orc.rodrigues_vec_to_mat(np.array([0.002, -0.004, 0.001])), np.array([[-0.54], [0.003], [0.002]])])
+    return Kg, M2g
+
+
+@pytest.mark.parametrize("rig", ["kitti", "general"])
+def test_scoring_bit_exact_large_random(rig):
+    K, M2 = (orc.K, orc.M2) if rig == "kitti" else _general_rig()
     rng = np.random.default_rng(77)
     n, H, stride = 1900, 96, 1920
     X = np.stack([rng.uniform(-30, 30, n), rng.uniform(-5, 4, n), rng.uniform(-5, 100, n)], 1)
@@ -235,6 +245,9 @@ def test_scoring_bit_exact_large_random():
     r1 = (orc.project(X, K @ orc.compose(T0, M2)) + rng.normal(0, 2.5, (n, 2))).astype(np.float32)
     Ts = np.array([np.hstack([orc.rodrigues_vec_to_mat(np.array([0.004, -0.02, 0.003]) + rng.normal(0, 0.002, 3)),
                               (T0[:, 3] + rng.normal(0, 0.02, 3))[:, None]]) for _ in range(H)])
+    # poses with a non-finite entry in each row in turn, a signed zero, and a point of zero depth for pose 0
+    Ts[1, 0, 1], Ts[2, 1, 3], Ts[3, 2, 0], Ts[4, 0, 3], Ts[5, 1, 0] = np.nan, np.inf, -np.inf, np.nan, -0.0
+    X[7] = -np.linalg.solve(Ts[0, :, :3], Ts[0, :, 3]) + Ts[0, :, :3].T @ np.array([0.3, 0.1, 0.0])
     with np.errstate(all="ignore"):
         want = np.array([orc.consensus_match(K, Ts[h], M2, X, l1.astype(np.float64), r1.astype(np.float64), 2) for h in range(H)])
     Xs = np.zeros((1, stride, 3))
