@@ -120,6 +120,12 @@ int slam_triangulate_f64(const double *h_P, const double *h_Q, const double *d_x
  */
 int slam_mt19937_words(uint32_t seed, uint32_t *h_words, int n_words);
 long slam_randint_host(uint32_t seed, uint32_t bound, int32_t *h_out, long n_out);
+/* The same stream generated on the device, for many pairs at once: for row r,
+ *   np.random.seed(d_seed[r]); draws [d_begin[r], d_begin[r] + n_draw) of repeated np.random.randint(0, d_count[r], 4)
+ * -> d_sample[r][n_draw][4] (int32).  Rows with d_count[r] <= 0 are left untouched.  Used by the later RANSAC rounds
+ * of slam_track_pairs, whose draw ranges depend on how far each pair's loop (utils/utills.py:498-523) has got. */
+int slam_randint_draws(const uint32_t *d_seed, const int32_t *d_count, const int32_t *d_begin, int n_rows, int n_draw,
+                       int32_t *d_sample, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PnP hypotheses.  Replaces pnp(..., cv2.SOLVEPNP_AP3P) + rodriguez_to_mat (utils/utills.py:574-596,

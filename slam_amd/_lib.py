@@ -59,6 +59,7 @@ SIGNATURES = {
     "slam_triangulate_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "slam_mt19937_words": (c_int, [c_uint32, c_void_p, c_int]),
     "slam_randint_host": (c_long, [c_uint32, c_uint32, c_void_p, c_long]),
+    "slam_randint_draws": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "slam_p3p_hypotheses": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p]),
     "slam_score_hypotheses": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,

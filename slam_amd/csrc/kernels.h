@@ -14,6 +14,11 @@ int slam_launch_map_samples(const uint32_t *d_words, int words_per_seg, const in
                             const int32_t *d_seg_of, int n_rows, int n_draw, int32_t *d_sample, int32_t *d_produced,
                             hipStream_t st);
 
+// np.random.seed(d_seed[seg]); draws [d_begin[row], d_begin[row] + n_draw) of np.random.randint(0, d_count[seg], 4),
+// generated on the device (MT19937 + masked rejection), into d_sample[row][n_draw*4].
+int slam_launch_draw_samples(const uint32_t *d_seed, const int32_t *d_count, const int32_t *d_seg_of,
+                             const int32_t *d_begin, int n_rows, int n_draw, int32_t *d_sample, hipStream_t st);
+
 // Hypotheses + scoring with an optional row -> segment indirection (rows = active pairs of a RANSAC round).
 int slam_launch_p3p(const Mat33 &K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count,
                     const int32_t *d_seg_of, int n_rows, int seg_stride, const int32_t *d_sample, int sample_stride,

@@ -59,6 +59,83 @@ __global__ __launch_bounds__(64) void map_samples_kernel(const uint32_t *words, 
     if (lane == 0) produced[row] = got / 4;
 }
 
+// ---- the whole stream on the device: np.random.seed(seed); np.random.randint(0, n, 4) x draws ----
+// One wavefront per row regenerates the pair's MT19937 stream from its seed (init_genrand, as numpy's legacy seeding of
+// an integer) and writes draws [begin, begin + n_draw) of the masked-rejection sequence.  Used by the later RANSAC
+// rounds, whose ranges depend on how far each pair's loop has got; regenerating from the seed costs a few
+// microseconds per thousand draws and keeps no per-pair generator state between rounds.
+// The 624-word state lives in LDS.  The twist is the sequential recurrence evaluated 64 words at a time: word k needs
+// the OLD words k and k + 1 and, for k < 227, the old word k + 397, else the NEW word k - 227 -- all available when a
+// chunk reads before it writes and chunks run in ascending order.
+__global__ __launch_bounds__(64) void draw_samples_kernel(const uint32_t *seed, const int *count, const int *seg_of,
+                                                          const int *begin, int n_draw, int *sample) {
+    __shared__ uint32_t mt[624];
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const int seg = seg_of ? seg_of[row] : row;
+    const int n = count[seg];
+    int *out = sample + (size_t)row * n_draw * 4;
+    const long want0 = (long)begin[row] * 4, want1 = want0 + (long)n_draw * 4;
+    if (n <= 0) return;
+    if (n == 1) {   // rng == 0: numpy returns `low` without consuming the stream
+        for (int i = lane; i < n_draw * 4; i += 64) out[i] = 0;
+        return;
+    }
+    const uint32_t rng = (uint32_t)n - 1u;
+    uint32_t mask = rng;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    if (lane == 0) {
+        uint32_t v = seed[seg];
+        for (int i = 0; i < 624; ++i) {
+            mt[i] = v;
+            v = 1812433253u * (v ^ (v >> 30)) + (uint32_t)i + 1u;
+        }
+    }
+    __syncthreads();
+    const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, A = 0x9908b0dfu;
+    long got = 0;
+    while (got < want1) {
+        for (int k0 = 0; k0 < 623; k0 += 64) {
+            const int k = k0 + lane;
+            uint32_t v = 0;
+            if (k < 623) {
+                const uint32_t y = (mt[k] & UP) | (mt[k + 1] & LO);
+                v = mt[k < 227 ? k + 397 : k - 227] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+            }
+            __syncthreads();                 // every read of this chunk before any of its writes
+            if (k < 623) mt[k] = v;
+            __syncthreads();
+        }
+        if (lane == 0) {
+            const uint32_t y = (mt[623] & UP) | (mt[0] & LO);
+            mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        }
+        __syncthreads();
+        for (int k0 = 0; k0 < 624 && got < want1; k0 += 64) {
+            const int k = k0 + lane;
+            uint32_t v = 0;
+            bool acc = false;
+            if (k < 624) {
+                uint32_t y = mt[k];
+                y ^= y >> 11;
+                y ^= (y << 7) & 0x9d2c5680u;
+                y ^= (y << 15) & 0xefc60000u;
+                y ^= y >> 18;
+                v = y & mask;
+                acc = v <= rng;
+            }
+            const unsigned long long bal = __ballot(acc);
+            const long pos = got + __popcll(bal & ((1ull << lane) - 1ull));
+            if (acc && pos >= want0 && pos < want1) out[pos - want0] = (int)v;
+            got += __popcll(bal);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- complex helpers (principal branches, as <complex>) ----
 struct cplx { double re, im; };
 
@@ -384,6 +461,15 @@ int slam_launch_map_samples(const uint32_t *d_words, int words_per_seg, const in
     return SLAM_OK;
 }
 
+int slam_launch_draw_samples(const uint32_t *d_seed, const int32_t *d_count, const int32_t *d_seg_of,
+                             const int32_t *d_begin, int n_rows, int n_draw, int32_t *d_sample, hipStream_t st) {
+    if (n_rows <= 0 || n_draw <= 0) return SLAM_OK;
+    hipLaunchKernelGGL(draw_samples_kernel, dim3(n_rows), dim3(64), 0, st, d_seed, d_count, d_seg_of, d_begin, n_draw,
+                       d_sample);
+    SLAM_HIP_CHECK(hipGetLastError());
+    return SLAM_OK;
+}
+
 int slam_launch_p3p(const Mat33 &K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count,
                     const int32_t *d_seg_of, int n_rows, int seg_stride, const int32_t *d_sample, int sample_stride,
                     int draw0, int n_hyp, double *d_pose, uint8_t *d_status, hipStream_t st) {
@@ -399,6 +485,14 @@ int slam_launch_p3p(const Mat33 &K, const double *d_X, const void *d_xy1, int xy
                            n_hyp, d_pose, d_status);
     SLAM_HIP_CHECK(hipGetLastError());
     return SLAM_OK;
+}
+
+extern "C" int slam_randint_draws(const uint32_t *d_seed, const int32_t *d_count, const int32_t *d_begin, int n_rows,
+                                  int n_draw, int32_t *d_sample, void *stream) {
+    SLAM_REQUIRE(n_rows >= 0 && n_draw >= 0, "slam_randint_draws: negative size");
+    if (n_rows == 0 || n_draw == 0) return SLAM_OK;
+    SLAM_REQUIRE(d_seed && d_count && d_begin && d_sample, "slam_randint_draws: null pointer");
+    return slam_launch_draw_samples(d_seed, d_count, nullptr, d_begin, n_rows, n_draw, d_sample, (hipStream_t)stream);
 }
 
 extern "C" int slam_p3p_hypotheses(const double *h_K, const double *d_X, const void *d_xy1, int xy_f64,

@@ -60,13 +60,14 @@ struct Buffers {
     uint64_t *mask;
     // later-round sub-batches alternate between two slots, so that the host prepares / replays one while the GPU
     // evaluates the other
-    int32_t *seg_of[2], *sampleR[2], *cntR[2], *best_idxR[2];
+    int32_t *seg_of[2], *beginR[2], *sampleR[2], *cntR[2], *best_idxR[2];
+    uint32_t *seed;
     double *poseR[2];
     uint8_t *statusR[2];
     // host (pinned)
     uint32_t *h_words0;
     int32_t *h_prob, *h_tcount, *h_aux, *h_produced0, *h_cnt0, *h_best_idx, *h_best_cnt;
-    int32_t *h_seg_of[2], *h_sampleR[2], *h_cntR[2], *h_best_idxR[2];
+    int32_t *h_seg_of[2], *h_beginR[2], *h_cntR[2], *h_best_idxR[2];
     uint8_t *h_status0, *h_statusR[2], *h_refit_status;
     int D0, W0, RB;
     // temporal keys of a chunk with F frames start right after its F stereo key rows
@@ -104,8 +105,10 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     b.mask = d.take<uint64_t>(Ps * (N / 64));
     b.refit_pose = d.take<double>(Ps * 12);
     b.refit_status = d.take<uint8_t>(Ps);
+    b.seed = d.take<uint32_t>(Ps);
     for (int k = 0; k < 2; ++k) {
         b.seg_of[k] = d.take<int32_t>(b.RB);
+        b.beginR[k] = d.take<int32_t>(b.RB);
         b.sampleR[k] = d.take<int32_t>((size_t)HYP_BUDGET * 4);
         b.poseR[k] = d.take<double>((size_t)HYP_BUDGET * 12);
         b.statusR[k] = d.take<uint8_t>(HYP_BUDGET);
@@ -125,7 +128,7 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     b.h_refit_status = h.take<uint8_t>(Ps);
     for (int k = 0; k < 2; ++k) {
         b.h_seg_of[k] = h.take<int32_t>(b.RB);
-        b.h_sampleR[k] = h.take<int32_t>((size_t)HYP_BUDGET * 4);
+        b.h_beginR[k] = h.take<int32_t>(b.RB);
         b.h_statusR[k] = h.take<uint8_t>(HYP_BUDGET);
         b.h_cntR[k] = h.take<int32_t>(HYP_BUDGET);
         b.h_best_idxR[k] = h.take<int32_t>(b.RB);
@@ -317,6 +320,7 @@ struct Lane {
         SLAM_HIP_CHECK(hipMemcpyAsync(b.prob_t, b.h_prob + F + P, sizeof(int32_t) * (F + P), hipMemcpyHostToDevice, st));
         SLAM_HIP_CHECK(hipMemcpyAsync(b.pair_f0, f0.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
         SLAM_HIP_CHECK(hipMemcpyAsync(b.pair_f1, f1.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.seed, seed, sizeof(uint32_t) * P, hipMemcpyHostToDevice, st));
         SLAM_HIP_CHECK(hipEventRecord(ev[0], st));
         // ---- 1. matching: F stereo + P temporal problems, ONE launch over the contiguous key array ----
         rc = slam_match_hamming_batched(d_desc, d_count, N, b.prob_q, b.prob_t, F + P, sh.norm, SLAM_MATCH_CROSSCHECK,
@@ -414,31 +418,25 @@ struct Lane {
             host_ms += now_ms() - t_h0;
             std::vector<int> still;
 
-            // host: sample indices of a sub-batch into staging slot s
+            // host: which pairs and which draw ranges go into staging slot s (the indices themselves are generated on
+            // the device from each pair's seed: drawing them here cost more than evaluating them there)
             auto draw = [&](const Batch &B, int s) {
                 const double t0 = now_ms();
-                const int n_eval = B.n_eval;
-                parallel_for(B.rows, 1, [&](int a, int e) {
-                    std::vector<int32_t> tmp;
-                    for (int r = a; r < e; ++r) {
-                        const int p = need[B.a0 + r].second;
-                        const long begin = rs[p].draws, total = (begin + n_eval) * 4;
-                        tmp.resize(total);
-                        slam_randint_host(seed[p], (uint32_t)b.h_tcount[p], tmp.data(), total);
-                        std::memcpy(b.h_sampleR[s] + (size_t)r * n_eval * 4, tmp.data() + begin * 4,
-                                    sizeof(int32_t) * (size_t)n_eval * 4);
-                    }
-                });
-                for (int r = 0; r < B.rows; ++r) b.h_seg_of[s][r] = need[B.a0 + r].second;
+                for (int r = 0; r < B.rows; ++r) {
+                    const int p = need[B.a0 + r].second;
+                    b.h_seg_of[s][r] = p;
+                    b.h_beginR[s][r] = rs[p].draws;
+                }
                 host_ms += now_ms() - t0;
             };
             // device: upload, solve, score, download; evR[s] marks the results' arrival
             auto launch = [&](const Batch &B, int s) -> int {
                 const int rows = B.rows, n_eval = B.n_eval;
                 SLAM_HIP_CHECK(hipMemcpyAsync(b.seg_of[s], b.h_seg_of[s], sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
-                SLAM_HIP_CHECK(hipMemcpyAsync(b.sampleR[s], b.h_sampleR[s], sizeof(int32_t) * (size_t)rows * n_eval * 4,
-                                              hipMemcpyHostToDevice, st));
-                int r2 = slam_launch_p3p(sh.K, b.X, b.xy1, 0, b.tcount, b.seg_of[s], rows, N, b.sampleR[s], n_eval, 0, n_eval,
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.beginR[s], b.h_beginR[s], sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
+                int r2 = slam_launch_draw_samples(b.seed, b.tcount, b.seg_of[s], b.beginR[s], rows, n_eval, b.sampleR[s], st);
+                if (r2) return r2;
+                r2 = slam_launch_p3p(sh.K, b.X, b.xy1, 0, b.tcount, b.seg_of[s], rows, N, b.sampleR[s], n_eval, 0, n_eval,
                                          b.poseR[s], b.statusR[s], st);
                 if (r2) return r2;
                 r2 = slam_launch_score(sh.K, sh.M2, b.X, b.xy1, 0, b.tcount, b.seg_of[s], rows, N, b.poseR[s], b.statusR[s],

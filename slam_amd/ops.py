@@ -153,6 +153,16 @@ def randint_host(seed: int, bound: int, n: int):
     return out, int(used)
 
 
+def randint_draws(seed: torch.Tensor, count: torch.Tensor, begin: torch.Tensor, n_draw: int) -> torch.Tensor:
+    """Per row r: np.random.seed(seed[r]); draws [begin[r], begin[r] + n_draw) of np.random.randint(0, count[r], 4),
+    generated on the device -> int32[n_rows, n_draw, 4]."""
+    n_rows = seed.numel()
+    out = torch.zeros((n_rows, n_draw, 4), dtype=torch.int32, device=seed.device)
+    check(_lib.lib().slam_randint_draws(_dev(seed, torch.int32), _dev(count, torch.int32), _dev(begin, torch.int32), n_rows,
+                                        n_draw, _dev(out), _stream()))
+    return out
+
+
 def mt19937_words(seed: int, n: int) -> np.ndarray:
     out = np.empty(n, np.uint32)
     check(_lib.lib().slam_mt19937_words(seed & 0xFFFFFFFF, _host(out), n))

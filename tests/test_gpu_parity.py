@@ -262,6 +262,23 @@ def test_scoring_bit_exact_large_random(rig):
     assert 0.05 < want.mean() < 0.95
 
 
+def test_device_sample_stream_equals_numpy():
+    """slam_randint_draws against np.random.seed / np.random.randint itself: bounds at and around powers of two (the
+    rejection rate's extremes), bound 1 (numpy consumes nothing), ranges that start mid-stream and straddle the 624-word
+    generator blocks, 32-bit seeds."""
+    cases = [(0, 2, 0), (1000, 1400, 0), (1234, 1025, 64), (99, 1024, 37), (7, 3, 500), (2 ** 32 - 1, 65537, 7), (5, 1, 3),
+             (31337, 1196, 1000), (42, 700, 2999), (17, 2047, 155), (18, 2048, 156), (19, 2049, 157)]
+    n_draw = 96
+    seed = np.array([c[0] for c in cases], np.uint32)
+    count = np.array([c[1] for c in cases], np.int32)
+    begin = np.array([c[2] for c in cases], np.int32)
+    got = ops.randint_draws(dev(seed.view(np.int32)), dev(count), dev(begin), n_draw).cpu().numpy()
+    for r, (s, n, b) in enumerate(cases):
+        np.random.seed(s)
+        want = np.stack([np.random.randint(0, n, 4) for _ in range(b + n_draw)])[b:]
+        assert np.array_equal(got[r], want), (s, n, b)
+
+
 def _ransac_problem(rng, n=500, frac_out=0.2):
     T0 = np.hstack([orc.rodrigues_vec_to_mat(np.array([0.01, -0.03, 0.005])), np.array([[0.05], [-0.02], [-0.8]])])
     X = np.stack([rng.uniform(-20, 20, n), rng.uniform(-4, 3, n), rng.uniform(4, 70, n)], 1)
