@@ -7,17 +7,12 @@ int slam_launch_rect_join(const float *d_xy, const int32_t *d_count, int n_max, 
                           int n_pairs, double rec_err, int32_t *d_tracked_count, int32_t *d_tracked_kp, float *d_xy0,
                           float *d_xy1, int32_t *d_aux, hipStream_t st);
 
-// Maps raw MT19937 words to np.random.randint(0, count[s], ...) values by numpy's masked rejection.
-// d_words: [n_seg][words_per_seg]; d_seg_of: optional indirection (segment index per row of d_words/d_sample,
-// NULL = identity); writes d_sample[row][n_draw*4] and d_produced[row] = number of complete 4-index draws.
-int slam_launch_map_samples(const uint32_t *d_words, int words_per_seg, const int32_t *d_count,
-                            const int32_t *d_seg_of, int n_rows, int n_draw, int32_t *d_sample, int32_t *d_produced,
-                            hipStream_t st);
-
 // np.random.seed(d_seed[seg]); draws [d_begin[row], d_begin[row] + n_draw) of np.random.randint(0, d_count[seg], 4),
-// generated on the device (MT19937 + masked rejection), into d_sample[row][n_draw*4].
+// generated on the device (MT19937 + masked rejection), into d_sample[row][n_draw*4].  d_begin == NULL: from draw 0.
+// d_produced (optional): [row] = n_draw where the segment has points, else 0.
 int slam_launch_draw_samples(const uint32_t *d_seed, const int32_t *d_count, const int32_t *d_seg_of,
-                             const int32_t *d_begin, int n_rows, int n_draw, int32_t *d_sample, hipStream_t st);
+                             const int32_t *d_begin, int n_rows, int n_draw, int32_t *d_sample, int32_t *d_produced,
+                             hipStream_t st);
 
 // Hypotheses + scoring with an optional row -> segment indirection (rows = active pairs of a RANSAC round).
 int slam_launch_p3p(const Mat33 &K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count,
@@ -32,6 +27,3 @@ int slam_launch_refit(const Mat33 &K, const double *d_X, const void *d_xy1, int 
                       uint8_t *d_status, hipStream_t st);
 int slam_launch_triangulate(const Mat34 &P, const Mat34 &Q, const float *d_xy, const int32_t *d_count, int n_seg,
                             int seg_stride, double *d_X, hipStream_t st);
-
-// host RNG (ransac_host.cpp)
-void slam_mt_seed_words(uint32_t seed, uint32_t *out, int n_words);

@@ -15,66 +15,24 @@
 
 namespace {
 
-// ---- numpy's bounded integers: np.random.randint(0, n) = masked rejection on 32-bit MT19937 outputs ----
-__global__ __launch_bounds__(64) void map_samples_kernel(const uint32_t *words, int words_per_seg, const int *count,
-                                                         const int *seg_of, int n_draw, int *sample, int *produced) {
-    const int row = blockIdx.x;
-    const int seg = seg_of ? seg_of[row] : row;
-    const int n = count[seg];
-    const int lane = threadIdx.x;
-    int *out = sample + (size_t)row * n_draw * 4;
-    const int want = n_draw * 4;
-    if (n <= 0) {
-        if (lane == 0) produced[row] = 0;
-        return;
-    }
-    if (n == 1) {   // rng == 0: numpy returns `low` without consuming the stream
-        for (int i = lane; i < want; i += 64) out[i] = 0;
-        if (lane == 0) produced[row] = n_draw;
-        return;
-    }
-    const uint32_t rng = (uint32_t)n - 1u;
-    uint32_t mask = rng;
-    mask |= mask >> 1;
-    mask |= mask >> 2;
-    mask |= mask >> 4;
-    mask |= mask >> 8;
-    mask |= mask >> 16;
-    const uint32_t *w = words + (size_t)row * words_per_seg;
-    int got = 0;
-    for (int base = 0; base < words_per_seg && got < want; base += 64) {
-        const int i = base + lane;
-        uint32_t v = 0;
-        bool acc = false;
-        if (i < words_per_seg) {
-            v = w[i] & mask;
-            acc = v <= rng;
-        }
-        const unsigned long long bal = __ballot(acc);
-        const int pos = got + __popcll(bal & ((1ull << lane) - 1ull));
-        if (acc && pos < want) out[pos] = (int)v;
-        got += __popcll(bal);
-    }
-    if (got > want) got = want;
-    if (lane == 0) produced[row] = got / 4;
-}
-
-// ---- the whole stream on the device: np.random.seed(seed); np.random.randint(0, n, 4) x draws ----
+// ---- the sample stream: np.random.seed(seed); np.random.randint(0, n, 4) x draws ----
+// numpy's bounded integers are masked rejection on 32-bit MT19937 outputs (legacy generator).
 // One wavefront per row regenerates the pair's MT19937 stream from its seed (init_genrand, as numpy's legacy seeding of
-// an integer) and writes draws [begin, begin + n_draw) of the masked-rejection sequence.  Used by the later RANSAC
-// rounds, whose ranges depend on how far each pair's loop has got; regenerating from the seed costs a few
-// microseconds per thousand draws and keeps no per-pair generator state between rounds.
+// an integer) and writes draws [begin, begin + n_draw) of the masked-rejection sequence.  Round 0 asks for draws [0, D0),
+// the later rounds for ranges that depend on how far each pair's loop has got; regenerating from the seed costs a
+// few microseconds per thousand draws and keeps no per-pair generator state between rounds.
 // The 624-word state lives in LDS.  The twist is the sequential recurrence evaluated 64 words at a time: word k needs
 // the OLD words k and k + 1 and, for k < 227, the old word k + 397, else the NEW word k - 227 -- all available when a
 // chunk reads before it writes and chunks run in ascending order.
 __global__ __launch_bounds__(64) void draw_samples_kernel(const uint32_t *seed, const int *count, const int *seg_of,
-                                                          const int *begin, int n_draw, int *sample) {
+                                                          const int *begin, int n_draw, int *sample, int *produced) {
     __shared__ uint32_t mt[624];
     const int row = blockIdx.x, lane = threadIdx.x;
     const int seg = seg_of ? seg_of[row] : row;
     const int n = count[seg];
     int *out = sample + (size_t)row * n_draw * 4;
-    const long want0 = (long)begin[row] * 4, want1 = want0 + (long)n_draw * 4;
+    const long want0 = begin ? (long)begin[row] * 4 : 0, want1 = want0 + (long)n_draw * 4;
+    if (produced && lane == 0) produced[row] = n > 0 ? n_draw : 0;
     if (n <= 0) return;
     if (n == 1) {   // rng == 0: numpy returns `low` without consuming the stream
         for (int i = lane; i < n_draw * 4; i += 64) out[i] = 0;
@@ -433,7 +391,7 @@ __global__ __launch_bounds__(64) void p3p_kernel(Mat33 K, const double *X, const
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         int i = idx[k];
-        i = i < 0 ? 0 : (i >= n ? n - 1 : i);       // indices come from map_samples and are in range; clamp defensively
+        i = i < 0 ? 0 : (i >= n ? n - 1 : i);       // indices come from draw_samples and are in range; clamp defensively
         const size_t g = (size_t)seg * seg_stride + i;
         Xs[k][0] = X[g * 3 + 0];
         Xs[k][1] = X[g * 3 + 1];
@@ -451,21 +409,12 @@ __global__ __launch_bounds__(64) void p3p_kernel(Mat33 K, const double *X, const
 
 }  // namespace
 
-int slam_launch_map_samples(const uint32_t *d_words, int words_per_seg, const int32_t *d_count,
-                            const int32_t *d_seg_of, int n_rows, int n_draw, int32_t *d_sample, int32_t *d_produced,
-                            hipStream_t st) {
-    if (n_rows <= 0 || n_draw <= 0) return SLAM_OK;
-    hipLaunchKernelGGL(map_samples_kernel, dim3(n_rows), dim3(64), 0, st, d_words, words_per_seg, d_count, d_seg_of,
-                       n_draw, d_sample, d_produced);
-    SLAM_HIP_CHECK(hipGetLastError());
-    return SLAM_OK;
-}
-
 int slam_launch_draw_samples(const uint32_t *d_seed, const int32_t *d_count, const int32_t *d_seg_of,
-                             const int32_t *d_begin, int n_rows, int n_draw, int32_t *d_sample, hipStream_t st) {
+                             const int32_t *d_begin, int n_rows, int n_draw, int32_t *d_sample, int32_t *d_produced,
+                             hipStream_t st) {
     if (n_rows <= 0 || n_draw <= 0) return SLAM_OK;
     hipLaunchKernelGGL(draw_samples_kernel, dim3(n_rows), dim3(64), 0, st, d_seed, d_count, d_seg_of, d_begin, n_draw,
-                       d_sample);
+                       d_sample, d_produced);
     SLAM_HIP_CHECK(hipGetLastError());
     return SLAM_OK;
 }
@@ -492,7 +441,7 @@ extern "C" int slam_randint_draws(const uint32_t *d_seed, const int32_t *d_count
     SLAM_REQUIRE(n_rows >= 0 && n_draw >= 0, "slam_randint_draws: negative size");
     if (n_rows == 0 || n_draw == 0) return SLAM_OK;
     SLAM_REQUIRE(d_seed && d_count && d_begin && d_sample, "slam_randint_draws: null pointer");
-    return slam_launch_draw_samples(d_seed, d_count, nullptr, d_begin, n_rows, n_draw, d_sample, (hipStream_t)stream);
+    return slam_launch_draw_samples(d_seed, d_count, nullptr, d_begin, n_rows, n_draw, d_sample, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int slam_p3p_hypotheses(const double *h_K, const double *d_X, const void *d_xy1, int xy_f64,

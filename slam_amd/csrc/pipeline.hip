@@ -5,7 +5,7 @@
 // Python; pairs are independent given the detections, so here every stage runs once for ALL pairs of the shard:
 //   1. one batched all-pairs launch: F stereo problems (left_f vs right_f) + P temporal problems (left_f0 vs left_f1)
 //   2. rect filter + 4-view join (one workgroup per pair)       3. DLT triangulation (one lane per point)
-//   4. RANSAC rounds: map raw MT19937 words to sample indices, AP3P per draw, consensus count per draw, then the
+//   4. RANSAC rounds: every pair's sample indices from its MT19937 stream (on the device), AP3P per draw, consensus count per draw, then the
 //      adaptive stopping rule is replayed on the host over the (status, count) arrays; pairs that need more draws
 //      than were evaluated speculatively go to the next, larger round
 //   5. supporter mask of the winning hypothesis + LM refit.
@@ -32,7 +32,6 @@ namespace {
 
 constexpr long HYP_BUDGET = 1 << 20;       // hypotheses per sub-batch of a later RANSAC round (pose buffer: 100 MB)
 constexpr int ROUND_QUANTUM = 64;          // later-round draw counts are multiples of this
-constexpr int WORDS_PER_DRAW = 16;         // raw words provisioned per draw (4 indices, acceptance >= 1/2, 2x margin)
 
 struct Carver {
     char *base;
@@ -53,7 +52,6 @@ struct Buffers {
     int32_t *prob_q, *prob_t, *pair_f0, *pair_f1, *tcount, *aux;
     float *xy0, *xy1;
     double *X;
-    uint32_t *words0;
     int32_t *sample0, *produced0, *cnt0, *best_idx, *best_cnt;
     double *pose0, *best_pose, *refit_pose;
     uint8_t *status0, *best_status, *refit_status;
@@ -65,11 +63,10 @@ struct Buffers {
     double *poseR[2];
     uint8_t *statusR[2];
     // host (pinned)
-    uint32_t *h_words0;
     int32_t *h_prob, *h_tcount, *h_aux, *h_produced0, *h_cnt0, *h_best_idx, *h_best_cnt;
     int32_t *h_seg_of[2], *h_beginR[2], *h_cntR[2], *h_best_idxR[2];
     uint8_t *h_status0, *h_statusR[2], *h_refit_status;
-    int D0, W0, RB;
+    int D0, RB;
     // temporal keys of a chunk with F frames start right after its F stereo key rows
     uint32_t *temporal_key_at(int F, int N) const { return stereo_key + (size_t)F * N; }
 };
@@ -79,7 +76,6 @@ int first_chunk(const SlamTrackConfig *cfg) { return cfg && cfg->first_chunk > 0
 void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carver &h, Buffers &b) {
     const size_t Fs = F, Ps = P, N = n_max;
     b.D0 = first_chunk(cfg);
-    b.W0 = b.D0 * WORDS_PER_DRAW;
     b.RB = (int)(HYP_BUDGET / ROUND_QUANTUM);
     b.stereo_key = d.take<uint32_t>((Fs + Ps) * N);   // one key array: F stereo problems, then P temporal ones
     b.temporal_key = b.stereo_key ? b.stereo_key + Fs * N : nullptr;
@@ -92,7 +88,6 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     b.xy0 = d.take<float>(Ps * N * 4);
     b.xy1 = d.take<float>(Ps * N * 4);
     b.X = d.take<double>(Ps * N * 3);
-    b.words0 = d.take<uint32_t>(Ps * b.W0);
     b.sample0 = d.take<int32_t>(Ps * b.D0 * 4);
     b.produced0 = d.take<int32_t>(Ps);
     b.pose0 = d.take<double>(Ps * b.D0 * 12);
@@ -116,7 +111,6 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
         b.best_idxR[k] = d.take<int32_t>(b.RB);
     }
 
-    b.h_words0 = h.take<uint32_t>(Ps * b.W0);
     b.h_prob = h.take<int32_t>(2 * (Fs + Ps));
     b.h_tcount = h.take<int32_t>(Ps);
     b.h_aux = h.take<int32_t>(2 * Ps);
@@ -149,7 +143,7 @@ __global__ void gather_best_kernel(const double *pose, const uint8_t *status, co
     if (k == 0) best_status[seg] = status[o];
 }
 
-// Host worker pool for the per-pair host steps (MT19937 words, loop replay, index drawing).  Persistent: creating
+// Host worker pool for the per-pair host steps (the loop replay).  Persistent: creating
 // and joining 16 threads per call costs several hundred microseconds, which sits on the critical path between a
 // chunk's RANSAC download and its mask / refit launch.  One job at a time (calls from different host threads queue on
 // `gate`); the calling thread works too.
@@ -305,7 +299,7 @@ struct Lane {
 
     // everything up to the first host decision, asynchronously: match, join, triangulate, RANSAC round 0, D2H
     int front(const Shared &sh) {
-        const int N = sh.N, D0 = b.D0, W0 = b.W0;
+        const int N = sh.N, D0 = b.D0;
         int rc = ensure_events();
         if (rc) return rc;
         for (int f = 0; f < F; ++f) {
@@ -327,13 +321,6 @@ struct Lane {
                                         b.stereo_key, nullptr, st);
         if (rc) return rc;
         SLAM_HIP_CHECK(hipEventRecord(ev[1], st));
-        // ---- host, while the GPU matches: raw MT19937 words of every pair's stream ----
-        const double t0 = now_ms();
-        parallel_for(P, 64, [&](int a, int e) {
-            for (int p = a; p < e; ++p) slam_mt_seed_words(seed[p], b.h_words0 + (size_t)p * W0, W0);
-        });
-        host_ms += now_ms() - t0;
-        SLAM_HIP_CHECK(hipMemcpyAsync(b.words0, b.h_words0, sizeof(uint32_t) * (size_t)P * W0, hipMemcpyHostToDevice, st));
         // ---- 2. join, 3. triangulate ----
         rc = slam_launch_rect_join(d_xy, d_count, N, b.stereo_key, b.temporal_key_at(F, N), b.pair_f0, b.pair_f1, P,
                                    sh.cfg->rec_err, b.tcount, sh.io->d_tracked_kp + (size_t)pair0 * N * 4, b.xy0, b.xy1,
@@ -344,7 +331,7 @@ struct Lane {
         if (rc) return rc;
         SLAM_HIP_CHECK(hipEventRecord(ev[3], st));
         // ---- 4. RANSAC round 0: D0 speculative draws for every pair ----
-        rc = slam_launch_map_samples(b.words0, W0, b.tcount, nullptr, P, D0, b.sample0, b.produced0, st);
+        rc = slam_launch_draw_samples(b.seed, b.tcount, nullptr, nullptr, P, D0, b.sample0, b.produced0, st);
         if (rc) return rc;
         rc = slam_launch_p3p(sh.K, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.sample0, D0, 0, D0, b.pose0, b.status0, st);
         if (rc) return rc;
@@ -434,7 +421,7 @@ struct Lane {
                 const int rows = B.rows, n_eval = B.n_eval;
                 SLAM_HIP_CHECK(hipMemcpyAsync(b.seg_of[s], b.h_seg_of[s], sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
                 SLAM_HIP_CHECK(hipMemcpyAsync(b.beginR[s], b.h_beginR[s], sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
-                int r2 = slam_launch_draw_samples(b.seed, b.tcount, b.seg_of[s], b.beginR[s], rows, n_eval, b.sampleR[s], st);
+                int r2 = slam_launch_draw_samples(b.seed, b.tcount, b.seg_of[s], b.beginR[s], rows, n_eval, b.sampleR[s], nullptr, st);
                 if (r2) return r2;
                 r2 = slam_launch_p3p(sh.K, b.X, b.xy1, 0, b.tcount, b.seg_of[s], rows, N, b.sampleR[s], n_eval, 0, n_eval,
                                          b.poseR[s], b.statusR[s], st);

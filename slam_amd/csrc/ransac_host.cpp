@@ -2,9 +2,9 @@
 //
 // utils/utills.py:502 draws np.random.randint(0, n, 4) from numpy's legacy global generator: MT19937
 // seeded by init_genrand, 32-bit outputs, bounded by masked rejection (numpy/random/src/distributions:
-// buffered_bounded_masked_uint32).  north_star: "the reference's random minimal samples are reproduced on the
-// host".  The raw 32-bit words do not depend on n, so they are generated here while the GPU is still matching;
-// the rejection step (which needs n = number of tracked points) runs on the device (p3p.hip, map_samples).
+// buffered_bounded_masked_uint32).  The host functions below serve the per-pair drop-in (online_est_pnp_ransac draws
+// from the global np.random stream) and the tests; the shard pipeline generates the same stream on the device
+// (p3p.hip, draw_samples_kernel), one wavefront per pair.
 #include "ransac_host.h"
 
 #include <cmath>
@@ -49,7 +49,7 @@ struct MT19937 {
 
 }  // namespace
 
-void slam_mt_seed_words(uint32_t seed, uint32_t *out, int n_words) {
+static void slam_mt_seed_words(uint32_t seed, uint32_t *out, int n_words) {
     MT19937 g(seed);
     for (int i = 0; i < n_words; ++i) out[i] = g.next();
 }
