@@ -72,7 +72,8 @@ __device__ __forceinline__ void jacobi_rot_params(double alpha, double beta, dou
                                                   bool &rotated) {
     // converged when |gamma| <= 1e-15 sqrt(alpha beta), tested without the square root.  (At 1e-16 about 1.5 % of
     // DLT matrices keep rotating at rounding level until the sweep cap, and one such lane stalls its whole wave.)
-    const bool go = gamma * gamma > 1e-30 * (alpha * beta);
+    const double g2 = gamma * gamma, ab = alpha * beta;
+    const bool go = g2 > 1e-30 * ab;
     const double d = beta - alpha;
     const double q = fma(d, d, 4.0 * gamma * gamma);
     const double den = fabs(d) + q * rsqrt_nr(q);          // q = 0 gives NaN here; then go is false and t is discarded
@@ -81,7 +82,10 @@ __device__ __forceinline__ void jacobi_rot_params(double alpha, double beta, dou
     t = go ? t : 0.0;                      // also absorbs 0/0 for a zero column pair
     c = rsqrt_nr(fma(t, t, 1.0));
     s = c * t;
-    rotated |= go;
+    // Convergence is quadratic: a pair whose cosine is below 1e-9 before this rotation is orthogonal to rounding after
+    // it, so only larger ones ask for another sweep.  (Asking for one after every rotation costs a last sweep that
+    // rotates nothing: 0.66 -> 0.59 ms per shard, points bit-identical on the bench data.)
+    rotated |= g2 > 1e-18 * ab;
 }
 
 template <int P, int Q>
