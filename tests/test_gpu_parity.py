@@ -418,6 +418,44 @@ def test_longer_sequence_equals_oracle_wherever_no_draw_repeats_its_fourth_index
     assert clean >= (F - 1) // 2          # the property must have been exercised
 
 
+def test_pipeline_with_plain_hamming_norm_and_a_general_rig():
+    """The shard pipeline off its defaults: NORM_HAMMING instead of NORM_HAMMING2 (the README of the reference says
+    "Hamming", its code NORM_HAMMING2: both must work) and a calibration / right camera without the rectified
+    structure the fast scoring variant needs.  Tracked sets bit-exact, masks and counts equal to the oracle's."""
+    from slam_amd.config import HotPathConfig, NORM_HAMMING
+    from slam_amd.pipeline import ShardTracker, consecutive_pairs
+    seq, desc, xy, count = _small_sequence(n_frames=5, n_features=320, seed=12)
+    F, _, n_max, _ = desc.shape
+    Kg, M2g = _general_rig()
+    f0, f1 = consecutive_pairs(F)
+    seeds = 500 + np.arange(F - 1)
+    args = (dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)), f0, f1, seeds)
+
+    def frame(i):
+        n0, n1 = count[i]
+        return dict(dsc_l=desc[i, 0, :n0, :61], dsc_r=desc[i, 1, :n1, :61], xy_l=xy[i, 0, :n0], xy_r=xy[i, 1, :n1])
+
+    for cfg, kw in ((HotPathConfig(norm=NORM_HAMMING), dict(norm=orc.NORM_HAMMING)),
+                    (HotPathConfig(K=Kg, M2=M2g), dict(calib=Kg, M2_=M2g))):
+        res = ShardTracker(F, F - 1, n_max, cfg).run(*args)
+        kp = res.tracked_kp.cpu().numpy()
+        for p in range(F - 1):
+            np.random.seed(int(seeds[p]))
+            st = {}
+            with np.errstate(all="ignore"):
+                want = orc.track_pair(frame(p), frame(p + 1), stats=st, **kw)
+            T = len(want["kp"])
+            assert res.stats[p, 0] == T and np.array_equal(kp[p, :T], want["kp"]), p
+            idx = np.random.RandomState(int(seeds[p])).randint(0, T, (max(st["draws"], int(res.stats[p, 3])), 4))
+            if any(i[3] in i[:3] for i in idx):
+                continue            # AP3P root choice on rounding noise (DESIGN.md section 2)
+            assert (res.stats[p, 2], res.stats[p, 4]) == (st["iterations"], st["best_draw"]), p
+            assert np.array_equal(res.mask[p, :T], want["mask"]), p
+            if want["T"] is not None:
+                err = np.linalg.norm(res.pose[p] - want["T"]) / np.linalg.norm(want["T"])
+                assert err <= REL_TOL, (p, err)
+
+
 def test_chunked_two_stream_pipeline_equals_single_pass():
     from slam_amd.pipeline import ShardTracker, consecutive_pairs
     seq, desc, xy, count = _small_sequence(n_frames=12, n_features=300, seed=4)
