@@ -92,6 +92,16 @@ __device__ __forceinline__ int within_fast_rect(const double *Pl, double pr3, do
     return (ql < lo && qr < lo) ? 1 : -1;
 }
 
+// A wave-uniform double moved to scalar registers (the FP64 VALU reads one scalar operand per instruction): the
+// projection matrices of a wavefront's hypotheses are the same in every lane, and holding them in SGPRs instead of
+// 2 x 48 VGPRs doubles the number of resident wavefronts.
+__device__ __forceinline__ double to_scalar(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 constexpr int SB = 256;   // 4 waves per workgroup, all on the same segment (shared L1 footprint)
 
 // One wavefront scores HW hypotheses of one segment: every point (24 B + one observation) is loaded once and tested
@@ -125,6 +135,16 @@ __global__ __launch_bounds__(SB) void score_kernel(Mat33 K, Mat34 M2, const doub
         compose_34(M2.m, T, Tr);
         gemm_33_34(K.m, T, Pl[k]);
         gemm_33_34(K.m, Tr, Pr[k]);
+        if (RECT) {
+            // the right matrix is the left one except element (0, 3) (see within_fast_rect): keep 13 scalars per
+            // hypothesis and rebuild the right matrix from them where the exact test needs it
+#pragma unroll
+            for (int i = 0; i < 12; ++i) Pl[k][i] = to_scalar(Pl[k][i]);
+            const double pr3 = to_scalar(Pr[k][3]);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) Pr[k][i] = Pl[k][i];
+            Pr[k][3] = pr3;
+        }
     }
 
     const double *Xs = X + (size_t)seg * seg_stride * 3;
