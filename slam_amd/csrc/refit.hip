@@ -97,6 +97,12 @@ __device__ __forceinline__ Pose apply_step(const Pose &P, const double (&d)[6]) 
 }
 
 constexpr int MAX_EVAL = 60;
+// Squared relative size of a step after which the solve stops.  The iteration converges quadratically (the damping
+// is down to 1e-3 x 0.1^k by step k), so the pose AFTER a step of relative size 1e-9 is already exact to rounding;
+// asking for a step below 1e-13 (1e-26 here) cost one more Jacobian + cost pass that changed nothing.
+#ifndef SLAM_REFIT_STEP2
+#define SLAM_REFIT_STEP2 1e-18
+#endif
 
 template <typename XY4>
 __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, const XY4 *xy1, const int *count,
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
             pn = 1.0 + P.t[0] * P.t[0] + P.t[1] * P.t[1] + P.t[2] * P.t[2];
             if (c2 <= cost) {
                 P = Q;
-                const bool tiny = dn <= 1e-26 * pn || (cost - c2) <= 1e-15 * cost;
+                const bool tiny = dn <= SLAM_REFIT_STEP2 * pn || (cost - c2) <= 1e-15 * cost;
                 cost = c2;
                 lambda = fmax(lambda * 0.1, 1e-16);
                 stepped = true;
