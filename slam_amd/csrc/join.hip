@@ -16,12 +16,17 @@ namespace {
 constexpr int JB = 256;
 constexpr unsigned IDX_MASK = SLAM_MAX_ROWS - 1;
 
+// JU left key-points per thread and pass: their four dependent gathers (stereo key -> right point -> next frame's stereo
+// key -> its right point) are in flight together, one memory round trip per level for 2048 key-points instead of one per
+// 256, and one barrier pair per pass.
+constexpr int JU = 8;
+
 __global__ __launch_bounds__(JB) void rect_join_kernel(const float2 *xy, const int *count, int n_max,
                                                        const unsigned *stereo, const unsigned *temporal,
                                                        const int *pf0, const int *pf1, double rec_err, int *tcount,
                                                        int4 *kp, float4 *xy0, float4 *xy1, int *aux) {
-    __shared__ int wave_tot[JB / 64];
-    __shared__ int wave_aux[2][JB / 64];
+    __shared__ int cnt[JU][JB / 64];          // tracked correspondences per (sub-pass, wave)
+    __shared__ int cnt_aux[2][JB / 64];
     const int p = blockIdx.x;
     const int f0 = pf0[p], f1 = pf1[p];
     const int nl0 = count[2 * f0];
@@ -32,56 +37,86 @@ __global__ __launch_bounds__(JB) void rect_join_kernel(const float2 *xy, const i
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int base = 0, n_stereo = 0, n_temporal = 0;
 
-    for (int q0 = 0; q0 < nl0; q0 += JB) {
-        const int q = q0 + threadIdx.x;
-        bool valid = false, has_s = false, has_t = false;
-        int r0 = 0, t = 0, r1 = 0;
-        float2 a = {0, 0}, b = {0, 0}, c = {0, 0}, d = {0, 0};
-        if (q < nl0) {
-            const unsigned k0 = s0[q], kt = tm[q];
-            has_s = k0 != SLAM_KEY_NONE;
-            has_t = kt != SLAM_KEY_NONE;
-            if (has_s && has_t) {
-                r0 = k0 & IDX_MASK;
-                t = kt & IDX_MASK;
-                a = xl0[q];
-                b = xr0[r0];
-                // float32 key-point rows widened to float64, |dy| <= REC_ERR inclusive (utills.py:178)
-                if (fabs((double)b.y - (double)a.y) <= rec_err) {
-                    const unsigned k1 = s1[t];
-                    if (k1 != SLAM_KEY_NONE) {
-                        r1 = k1 & IDX_MASK;
-                        c = xl1[t];
-                        d = xr1[r1];
-                        valid = fabs((double)d.y - (double)c.y) <= rec_err;
-                    }
-                }
+    for (int q0 = 0; q0 < nl0; q0 += JB * JU) {
+        // key-point of sub-pass u: q0 + u * JB + thread, so ascending (u, wave, lane) is ascending key-point order
+        bool valid[JU];
+        int r0[JU], t[JU], r1[JU];
+        float2 a[JU], b[JU], c[JU], d[JU];
+        unsigned k0[JU], kt[JU], k1[JU];
+        int ns = 0, nt = 0;
+#pragma unroll
+        for (int u = 0; u < JU; ++u) {
+            const int q = q0 + u * JB + threadIdx.x;
+            k0[u] = kt[u] = SLAM_KEY_NONE;
+            if (q < nl0) {
+                k0[u] = s0[q];
+                kt[u] = tm[q];
             }
         }
-        const unsigned long long bal = __ballot(valid);
-        const unsigned long long bs = __ballot(has_s), bt = __ballot(has_t);
+#pragma unroll
+        for (int u = 0; u < JU; ++u) {
+            const int q = q0 + u * JB + threadIdx.x;
+            const bool has_s = k0[u] != SLAM_KEY_NONE, has_t = kt[u] != SLAM_KEY_NONE;
+            ns += __popcll(__ballot(has_s));
+            nt += __popcll(__ballot(has_t));
+            valid[u] = has_s && has_t;
+            r0[u] = k0[u] & IDX_MASK;
+            t[u] = kt[u] & IDX_MASK;
+            k1[u] = SLAM_KEY_NONE;
+            a[u] = b[u] = make_float2(0, 0);
+            if (valid[u]) {
+                a[u] = xl0[q];
+                b[u] = xr0[r0[u]];
+                k1[u] = s1[t[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < JU; ++u) {
+            // float32 key-point rows widened to float64, |dy| <= REC_ERR inclusive (utills.py:178)
+            valid[u] = valid[u] && fabs((double)b[u].y - (double)a[u].y) <= rec_err && k1[u] != SLAM_KEY_NONE;
+            r1[u] = k1[u] & IDX_MASK;
+            c[u] = d[u] = make_float2(0, 0);
+            if (valid[u]) {
+                c[u] = xl1[t[u]];
+                d[u] = xr1[r1[u]];
+            }
+        }
+        unsigned long long bal[JU];
+#pragma unroll
+        for (int u = 0; u < JU; ++u) {
+            valid[u] = valid[u] && fabs((double)d[u].y - (double)c[u].y) <= rec_err;
+            bal[u] = __ballot(valid[u]);
+            if (lane == 0) cnt[u][wave] = __popcll(bal[u]);
+        }
         if (lane == 0) {
-            wave_tot[wave] = __popcll(bal);
-            wave_aux[0][wave] = __popcll(bs);
-            wave_aux[1][wave] = __popcll(bt);
+            cnt_aux[0][wave] = ns;
+            cnt_aux[1][wave] = nt;
         }
         __syncthreads();
-        int off = base, tot = 0;
+        int off = base;
+#pragma unroll
+        for (int u = 0; u < JU; ++u) {
+#pragma unroll
+            for (int w = 0; w < JB / 64; ++w) {
+                const int n = cnt[u][w];
+                if (valid[u]) {
+                    if (w == wave) {
+                        const int o = off + __popcll(bal[u] & ((1ull << lane) - 1ull));
+                        const size_t g = (size_t)p * n_max + o;
+                        kp[g] = make_int4(q0 + u * JB + threadIdx.x, r0[u], t[u], r1[u]);
+                        xy0[g] = make_float4(a[u].x, a[u].y, b[u].x, b[u].y);
+                        xy1[g] = make_float4(c[u].x, c[u].y, d[u].x, d[u].y);
+                    }
+                }
+                off += n;
+            }
+        }
 #pragma unroll
         for (int w = 0; w < JB / 64; ++w) {
-            if (w < wave) off += wave_tot[w];
-            tot += wave_tot[w];
-            n_stereo += wave_aux[0][w];
-            n_temporal += wave_aux[1][w];
+            n_stereo += cnt_aux[0][w];
+            n_temporal += cnt_aux[1][w];
         }
-        if (valid) {
-            const int o = off + __popcll(bal & ((1ull << lane) - 1ull));
-            const size_t g = (size_t)p * n_max + o;
-            kp[g] = make_int4(q, r0, t, r1);
-            xy0[g] = make_float4(a.x, a.y, b.x, b.y);
-            xy1[g] = make_float4(c.x, c.y, d.x, d.y);
-        }
-        base += tot;
+        base = off;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
