@@ -33,3 +33,13 @@ static inline size_t slam_align_up(size_t x, size_t a) { return (x + a - 1) / a 
 // 3x4 / 3x3 matrices handed to kernels by value
 struct Mat34 { double m[12]; };
 struct Mat33 { double m[9]; };
+
+// A wave-uniform double moved to scalar registers (the FP64 VALU reads one scalar operand per instruction).  Values
+// that are the same in every lane -- a hypothesis' projection matrix, a reduced sum -- then cost no vector registers.
+__device__ __forceinline__ double to_scalar(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+

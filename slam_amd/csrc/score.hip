@@ -92,16 +92,6 @@ __device__ __forceinline__ int within_fast_rect(const double *Pl, double pr3, do
     return (ql < lo && qr < lo) ? 1 : -1;
 }
 
-// A wave-uniform double moved to scalar registers (the FP64 VALU reads one scalar operand per instruction): the
-// projection matrices of a wavefront's hypotheses are the same in every lane, and holding them in SGPRs instead of
-// 2 x 48 VGPRs doubles the number of resident wavefronts.
-__device__ __forceinline__ double to_scalar(double v) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
 constexpr int SB = 256;   // 4 waves per workgroup, all on the same segment (shared L1 footprint)
 
 // One wavefront scores HW hypotheses of one segment: every point (24 B + one observation) is loaded once and tested
