@@ -13,6 +13,12 @@
 #include "jacobi.h"   // rcp_nr
 #include "kernels.h"
 
+// The library is compiled with -ffp-contract=off because the matcher, triangulation and scoring reproduce numpy's
+// operation order.  Nothing of that kind applies to this solver (its result is the minimiser, to which it converges
+// to rounding whatever the rounding of an intermediate), so multiply-adds are fused here: about 40 % fewer FP64
+// instructions in the two passes over the points.
+#pragma clang fp contract(fast)
+
 namespace {
 
 __device__ __forceinline__ double wave_sum(double v) {
