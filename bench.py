@@ -76,7 +76,15 @@ def main():
     backend = os.environ.get("SLAM_BENCH_BACKEND", "nccl")
     local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
     torch.cuda.set_device(local)
-    if world > 1:
+    # Rank 0 prints ONE JSON line: RCCL writes a version banner to stdout when a communicator is created, so file
+    # descriptor 1 points at stderr for the run and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    # SLAM_BENCH_FORCE_DIST=1 under a one-process torch.distributed.run: the process group and the gather run at world
+    # size 1 too, which rehearses the RCCL calls of the multi-GPU run on a one-GPU box.
+    use_dist = world > 1 or (os.environ.get("SLAM_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -123,7 +131,7 @@ def main():
         return res, glob
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,7 +146,7 @@ def main():
         stage_ms.append(res.timing_ms.copy())
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -204,8 +212,9 @@ def main():
             out["pcie_inclusive"] = pcie_inclusive(args, desc, xy, count, trk, f0, f1, seeds)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, seq, desc, xy, count, seeds, res, trk)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

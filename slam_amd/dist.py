@@ -35,7 +35,7 @@ def shard_list(n_units: int, rank: int, world: int):
 
 def all_gather_rows(local: torch.Tensor, n_total: int, world: int, rank: int) -> torch.Tensor:
     """Gathers row blocks laid out by `block_range` into one [n_total, ...] tensor on every rank."""
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return local
     per = -(-n_total // world)
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -49,7 +49,7 @@ def gather_shard_results(pose_local: np.ndarray, stats_local: np.ndarray, n_pair
     """pose_local float64[p, 3, 4], stats_local int32[p, 8] of this rank's pair block -> the full arrays on every rank."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    if world == 1:
+    if not dist.is_initialized():
         return pose_local, stats_local
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
                                              if dist.get_backend() == "nccl" else torch.device("cpu"))
