@@ -18,3 +18,10 @@ def pytest_configure(config):
 def golden():
     """Vectors recorded from the reference itself (tests/golden/make_golden.py)."""
     return np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def golden_more():
+    """Second batch recorded from the reference (tests/golden/make_golden_more.py): kNN + ratio test, the older
+    per-pair API, loop-closure candidate validation, fewer than 6 supporters."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors_more.npz"), allow_pickle=False)

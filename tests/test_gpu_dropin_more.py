@@ -1,0 +1,115 @@
+"""The reference-shaped entry points (slam_amd.utills) against the SECOND batch of vectors recorded from the
+reference itself (tests/golden/make_golden_more.py): kNN + ratio test, the older per-pair API, a non-consecutive
+pair, loop-closure candidate validation, fewer than 6 supporters."""
+import numpy as np
+import pytest
+
+from slam_amd import utills as U
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-5                                                    # north_star: poses within 1e-5 relative
+
+
+@pytest.fixture()
+def movie(golden):
+    src = U.ArrayDetections(golden["movie_desc"], golden["movie_xy"], golden["movie_count"])
+    U.set_detection_source(src)
+    yield src
+    U.set_detection_source(None)
+
+
+def _triples(ms):
+    return np.array([[m.queryIdx, m.trainIdx, m.distance] for m in ms], np.int64).reshape(-1, 3)
+
+
+def _kp(feats):
+    return np.array([[f.get_left_kpt(), f.get_right_kpt()] for f in feats], np.int64).reshape(-1, 2)
+
+
+def _close(T, want):
+    return np.linalg.norm(T - want) / np.linalg.norm(want) <= REL_TOL
+
+
+def test_knn_ratio_path_equals_reference(golden_more, movie):
+    l2, d2, *_ = U.read_and_rec_match(2)
+    l3, d3, *_ = U.read_and_rec_match(3)
+    got = U.match(d2, d3, U.REGULAR_KNN)
+    assert isinstance(got, np.ndarray) and got.dtype == object
+    assert np.array_equal(_triples(got), golden_more["knn_temporal"])
+    _, _, xy_r, dsc_r = movie.get(2)
+    assert np.array_equal(_triples(U.match(d2, dsc_r, U.REGULAR_KNN)), golden_more["knn_stereo"])
+
+
+def test_ratio_test_boundary_table(golden_more):
+    g = golden_more
+    pairs = [[U.DMatch(i, 0, int(a)), U.DMatch(i, 1, int(b))] for i, (a, b) in enumerate(zip(g["sig_d1"], g["sig_d2"]))]
+    ok, failed = U.significance_test(pairs, U.RATIO)
+    passed = np.zeros(len(pairs), bool)
+    passed[[m.queryIdx for m in ok]] = True
+    assert np.array_equal(passed, g["sig_pass"]) and len(ok) + len(failed) == len(pairs)
+
+
+def test_compute_trans_between_cur_to_next_equals_reference(golden_more, movie):
+    g = golden_more
+    a, b = U.read_and_rec_match(2), U.read_and_rec_match(3)
+    np.random.seed(777)
+    T, mask = U.compute_trans_between_cur_to_next(*a, *b)
+    assert np.array_equal(mask, g["cur_next_mask"]) and _close(T, g["cur_next_T"])
+    assert np.random.randint(0, 1 << 30) == int(g["cur_next_next_rand"])
+
+
+def test_apply_full_consensus_match_equals_reference(golden_more, movie):
+    g = golden_more
+    np.random.seed(778)
+    T, f0, f1, sup, perc = U.apply_full_consensus_match(1, 4)
+    assert np.array_equal(_kp(f0), g["full_f0_kp"]) and np.array_equal(_kp(f1), g["full_f1_kp"])
+    assert np.array_equal([[*f.get_left_coor(), *f.get_right_coor()] for f in f1], g["full_f1_xy"])
+    assert np.array_equal(sup, g["full_mask"]) and perc == float(g["full_perc"]) and _close(T, g["full_T"])
+    assert np.random.randint(0, 1 << 30) == int(g["full_next_rand"])
+
+
+def test_loop_candidates_equal_reference(golden_more, movie):
+    """The reference validates candidates one after the other on ONE global random stream (:1124-1144).  The per-pair
+    entry points follow that stream draw for draw, so running them in candidate order reproduces its supporters
+    exactly; the batched find_loop_cand_by_consensus gives every pair its own seed (no output of the reference depends
+    on the stream, which it never seeds), so it is held to what does not depend on the draws: every candidate passes
+    at threshold 0, none at 100, and the tracks of a passing candidate are a subset of the 4-view tracked set."""
+    g = golden_more
+    cur, cands, pg = int(g["loop_cur"]), [int(c) for c in g["loop_cands"]], [int(p) for p in g["loop_pg"]]
+    for k, thr in enumerate(g["loop_thresholds"]):
+        np.random.seed(779)
+        passed, j = [], 0
+        for c, cand in enumerate(cands):
+            T, f0, f1, sup, perc = U.apply_full_consensus_match(cand, cur)
+            assert perc == g[f"loop_{k}_printed_perc"][c]
+            if perc > thr:
+                passed.append(pg[c])
+                tracks = U.create_little_tracks(f0[sup], f1[sup], cand, cur)
+                want = g[f"loop_{k}_{j}_kp"]
+                got = np.array([[t.get_feature_at_frame(cand).get_left_kpt(), t.get_feature_at_frame(cur).get_left_kpt(),
+                                 t.get_feature_at_frame(cand).get_right_kpt(), t.get_feature_at_frame(cur).get_right_kpt()]
+                                for t in tracks]).reshape(-1, 4)
+                assert np.array_equal(got, want)
+                assert all(list(t.get_frames_ids()) == [cand, cur] for t in tracks)       # insertion order, as Trck.py:30
+                assert [t.get_id() for t in tracks] == list(g[f"loop_{k}_{j}_ids"])
+                j += 1
+        assert passed == list(g[f"loop_{k}_passed_pg"])
+        assert np.random.randint(0, 1 << 30) == int(g[f"loop_{k}_next_rand"])
+    everyone = U.find_loop_cand_by_consensus(cands, pg, cur, 0.0, seeds=np.arange(4) + 11)
+    assert [o[0] for o in everyone] == pg
+    for j, (_, tracks) in enumerate(everyone):
+        ref = {tuple(r) for r in g[f"loop_0_{j}_kp"]}
+        got = {(t.get_feature_at_frame(cands[j]).get_left_kpt(), t.get_feature_at_frame(cur).get_left_kpt(),
+                t.get_feature_at_frame(cands[j]).get_right_kpt(), t.get_feature_at_frame(cur).get_right_kpt()) for t in tracks}
+        assert len(got & ref) >= 0.97 * len(ref)                 # same scene, different draws: nearly the same supporters
+    assert U.find_loop_cand_by_consensus(cands, pg, cur, 100.0, seeds=np.arange(4) + 11) == []
+
+
+def test_fewer_than_six_supporters_gives_no_pose(golden_more):
+    g = golden_more
+    X, l, r = g["few_X"], g["few_l1"], g["few_r1"]
+    np.random.seed(780)
+    T, mask = U.online_est_pnp_ransac(4, X, U.M1, l, U.M2, r, l, U.M2, r, U.K, acc=2)
+    assert T is None and bool(g["few_T_is_none"])
+    assert np.array_equal(mask, g["few_mask"])
+    assert np.random.randint(0, 1 << 30) == int(g["few_next_rand"])
