@@ -556,6 +556,38 @@ thread_local Lane g_lane[2];
 thread_local hipStream_t g_side_stream[2] = {nullptr, nullptr};
 thread_local hipEvent_t g_fork = nullptr;
 thread_local hipEvent_t g_base = nullptr;
+thread_local int g_device = -1;                      // device the streams / events above were created on
+
+// Streams and events belong to the device that was current when they were created.  A host thread that moves to
+// another device between calls gets a fresh set there (the old one is released: nothing of a finished call is still
+// queued on it, every call drains its lanes before it returns).
+int bind_device() {
+    int dev = -1;
+    SLAM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev == g_device) return SLAM_OK;
+    if (g_device >= 0) {
+        for (Lane &ln : g_lane)
+            if (ln.ev_ready) {
+                for (auto &e : ln.ev) (void)hipEventDestroy(e);
+                for (auto &e : ln.evR) (void)hipEventDestroy(e);
+                ln.ev_ready = false;
+            }
+        if (g_fork) {
+            (void)hipEventDestroy(g_fork);
+            g_fork = nullptr;
+            for (auto &s : g_side_stream) {
+                (void)hipStreamDestroy(s);
+                s = nullptr;
+            }
+        }
+        if (g_base) {
+            (void)hipEventDestroy(g_base);
+            g_base = nullptr;
+        }
+    }
+    g_device = dev;
+    return SLAM_OK;
+}
 
 struct Chunk { int a, e, lo, hi; };
 
@@ -680,6 +712,10 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
         if (2 * dl > io->d_workspace_bytes || 2 * hl > io->h_workspace_bytes) chunks.clear();   // pairs not local in time
     }
     Lane *L = g_lane;
+    {
+        const int rc = bind_device();
+        if (rc) return rc;
+    }
     if (!g_base) SLAM_HIP_CHECK(hipEventCreate(&g_base));
     SLAM_HIP_CHECK(hipEventRecord(g_base, st));
     for (int k = 0; k < 2; ++k) {
@@ -702,7 +738,10 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
         int rc = L[0].front(sh);
         if (!rc) rc = L[0].mid(sh);
         if (!rc) rc = L[0].back(sh);
-        if (rc) return rc;
+        if (rc) {
+            (void)hipStreamSynchronize(st);                      // no work of a failed call outlives it
+            return rc;
+        }
         n_launch = 1;
     } else {
         if (!g_fork) {
