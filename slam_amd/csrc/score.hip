@@ -196,6 +196,94 @@ __global__ __launch_bounds__(SB) void score_kernel(Mat33 K, Mat34 M2, const doub
     }
 }
 
+// Counting only, many hypotheses per segment (the later RANSAC rounds: up to 2^20 draws over the pairs whose loop is
+// still running): ONE LANE PER HYPOTHESIS.  The wavefront-per-hypothesis kernel above builds every hypothesis's
+// projection matrices in all 64 lanes and spends a whole 64-point step on a segment that holds 20 points, which is
+// what the pairs that run to the iteration cap look like (unrelated frames in loop-closure validation): ~130 FP64
+// wave-instructions per hypothesis whatever the segment size.  Here a lane builds the matrices of its own hypothesis
+// once, the segment's points go through LDS in tiles of LT points that every lane reads as broadcasts, and the cost is
+// (130 + 30 T) / 64 wave-instructions per hypothesis.  The per-point arithmetic is the same functions as above, so
+// the counts are the same bit for bit.
+// A matrix with a NaN entry makes the homogeneous coordinate it feeds NaN for every point (fma and add propagate NaN
+// whatever the other operand), hence the distance NaN, hence the comparison false: such a hypothesis (a degenerate
+// sample, 6/T of the draws) has no supporters and is not evaluated; otherwise its lane would drag the wavefront
+// through the exact divide + sqrt path on every point.  Infinite entries take the ordinary path.
+constexpr int LT = 256;   // points per LDS tile (7 doubles each: 14 KB)
+#ifndef SLAM_LANES_MIN_HYP
+#define SLAM_LANES_MIN_HYP 256
+#endif
+constexpr int LANES_MIN_HYP = SLAM_LANES_MIN_HYP;   // hypotheses per segment from which the lane-per-hypothesis kernel is used
+
+template <typename XY4, bool RECT>
+__global__ __launch_bounds__(SB) void score_lanes_kernel(Mat33 K, Mat34 M2, const double *X, const XY4 *xy1,
+                                                         const int *count, const int *seg_of, int n_rows, int groups,
+                                                         int seg_stride, const double *pose, const uint8_t *status,
+                                                         int n_hyp, double thr, int *inlier_count) {
+    __shared__ double pts[LT * 7];
+    // all workgroups of a segment on one XCD, as in score_kernel
+    const int xcd = blockIdx.x % 8, k = blockIdx.x / 8;
+    const int row = (k / groups) * 8 + xcd;
+    if (row >= n_rows) return;
+    const int h = (k % groups) * SB + threadIdx.x;
+    const bool have = h < n_hyp;
+    const size_t o = (size_t)row * n_hyp + (have ? h : 0);
+    const int seg = seg_of ? seg_of[row] : row;
+    const int n = count[seg];
+
+    double Pl[12], Pr[12];
+    {
+        double T[12], Tr[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = pose[o * 12 + i];
+        compose_34(M2.m, T, Tr);
+        gemm_33_34(K.m, T, Pl);
+        gemm_33_34(K.m, Tr, Pr);
+    }
+    bool live = have && status[o] != 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) live = live && !(Pl[i] != Pl[i]) && !(Pr[i] != Pr[i]);
+
+    const double *Xs = X + (size_t)seg * seg_stride * 3;
+    const XY4 *obs = xy1 + (size_t)seg * seg_stride;
+    const double lo = thr < 0.0 ? -1.0 : thr * thr * (1.0 - 1e-9), hi = thr < 0.0 ? -1.0 : thr * thr * (1.0 + 1e-9);
+    int total = 0;
+    for (int base = 0; base < n; base += LT) {
+        if (base) __syncthreads();                     // the previous tile has been consumed
+        for (int i = threadIdx.x; i < LT && base + i < n; i += SB) {
+            const int g = base + i;
+            const XY4 c = obs[g];
+            double *q = pts + i * 7;
+            q[0] = Xs[g * 3 + 0];
+            q[1] = Xs[g * 3 + 1];
+            q[2] = Xs[g * 3 + 2];
+            q[3] = (double)c.x;
+            q[4] = (double)c.y;
+            q[5] = (double)c.z;
+            q[6] = (double)c.w;
+        }
+        __syncthreads();
+        const int m = min(LT, n - base);
+        if (live) {
+            for (int i = 0; i < m; ++i) {
+                const double *q = pts + i * 7;
+                const double x = q[0], y = q[1], z = q[2], ul = q[3], vl = q[4], ur = q[5], vr = q[6];
+                int f;
+                if (RECT) {
+                    f = within_fast_rect(Pl, Pr[3], x, y, z, ul, vl, ur, vr, lo, hi);
+                } else {
+                    const int fl = within_fast(Pl, x, y, z, ul, vl, lo, hi);
+                    const int fr = within_fast(Pr, x, y, z, ur, vr, lo, hi);
+                    f = (fl == 0 || fr == 0) ? 0 : ((fl == 1 && fr == 1) ? 1 : -1);
+                }
+                bool in = f == 1;
+                if (f < 0) in = within(Pl, x, y, z, ul, vl, thr) && within(Pr, x, y, z, ur, vr, thr);
+                total += in ? 1 : 0;
+            }
+        }
+    }
+    if (have) inlier_count[o] = total;
+}
+
 // drop-in consensus_match: float64 observations, one pose, byte mask
 __global__ __launch_bounds__(256) void consensus_f64_kernel(Mat33 K, Mat34 M2, Mat34 T, const double *X,
                                                             const double2 *l1, const double2 *r1, int n, double thr,
@@ -230,13 +318,31 @@ int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const 
                       hipStream_t st) {
     if (n_rows <= 0 || n_hyp <= 0) return SLAM_OK;
     SLAM_REQUIRE(!d_mask || seg_stride % 64 == 0, "slam_score_hypotheses: seg_stride must be a multiple of 64 for masks");
+    const bool rect = rectified_rig(K, M2);
+    if (!d_mask && n_hyp >= LANES_MIN_HYP) {
+        // counting only and enough hypotheses per segment to fill workgroups with them: one lane per hypothesis
+        const int groups = slam_div_up(n_hyp, SB);
+        const long n_blocks = (long)groups * (slam_div_up(n_rows, 8) * 8L);
+        SLAM_REQUIRE(n_blocks < (1L << 31), "slam_score_hypotheses: %d segments x %d hypotheses is too large for one call", n_rows, n_hyp);
+        const dim3 grid((unsigned)n_blocks), block(SB);
+#define SLAM_LANES_LAUNCH(XY, RECT)                                                                                      \
+    hipLaunchKernelGGL((score_lanes_kernel<XY, RECT>), grid, block, 0, st, K, M2, d_X, (const XY *)d_xy1, d_count, d_seg_of, \
+                       n_rows, groups, seg_stride, d_pose, d_status, n_hyp, thr, d_inlier_count)
+        if (xy_f64) {
+            if (rect) SLAM_LANES_LAUNCH(double4, true); else SLAM_LANES_LAUNCH(double4, false);
+        } else {
+            if (rect) SLAM_LANES_LAUNCH(float4, true); else SLAM_LANES_LAUNCH(float4, false);
+        }
+#undef SLAM_LANES_LAUNCH
+        SLAM_HIP_CHECK(hipGetLastError());
+        return SLAM_OK;
+    }
     // counting only: two hypotheses per wavefront; with a mask: one (a mask row per hypothesis)
     const int hw = d_mask ? 1 : 2;
     const int groups = slam_div_up(n_hyp, (SB / 64) * hw);                 // workgroups per segment
     const long n_blocks = (long)groups * (slam_div_up(n_rows, 8) * 8L);
     SLAM_REQUIRE(n_blocks < (1L << 31), "slam_score_hypotheses: %d segments x %d hypotheses is too large for one call", n_rows, n_hyp);
     const dim3 grid((unsigned)n_blocks), block(SB);
-    const bool rect = rectified_rig(K, M2);
 #define SLAM_SCORE_LAUNCH(XY, HW, RECT)                                                                                    \
     hipLaunchKernelGGL((score_kernel<XY, HW, RECT>), grid, block, 0, st, K, M2, d_X, (const XY *)d_xy1, d_count, d_seg_of, \
                        n_rows, groups, seg_stride, d_pose, d_status, n_hyp, thr, d_inlier_count, (unsigned long long *)d_mask)

@@ -262,6 +262,49 @@ def test_scoring_bit_exact_large_random(rig):
     assert 0.05 < want.mean() < 0.95
 
 
+@pytest.mark.parametrize("rig", ["kitti", "general"])
+@pytest.mark.parametrize("xy_dtype", [np.float32, np.float64])
+def test_scoring_many_hypotheses_per_segment_lane_per_hypothesis_kernel(rig, xy_dtype):
+    """From 256 hypotheses per segment the counting path runs one LANE per hypothesis (score_lanes_kernel: the later
+    RANSAC rounds).  Counts against the oracle and against the wavefront-per-hypothesis kernel (the mask path), on
+    segments of 0 ... 700 points (below, at and above one 256-point LDS tile), with failed solves, NaN and infinite
+    poses, a point on the camera plane, and a hypothesis count that does not fill the last workgroup."""
+    K, M2 = (orc.K, orc.M2) if rig == "kitti" else _general_rig()
+    rng = np.random.default_rng(91)
+    sizes = [0, 1, 5, 20, 63, 64, 255, 256, 257, 513, 700]
+    S, H, stride = len(sizes), 300, 704
+    T0 = np.hstack([orc.rodrigues_vec_to_mat(np.array([0.004, -0.02, 0.003])), np.array([[0.03], [-0.01], [-0.9]])])
+    Xs = np.zeros((S, stride, 3))
+    xy1 = np.zeros((S, stride, 4), xy_dtype)
+    Ts = np.zeros((S, H, 3, 4))
+    status = (rng.random((S, H)) > 0.1).astype(np.uint8)
+    want = np.zeros((S, H), np.int64)
+    for s, n in enumerate(sizes):
+        X = np.stack([rng.uniform(-30, 30, n), rng.uniform(-5, 4, n), rng.uniform(-5, 100, n)], 1)
+        l1 = (orc.project(X, K @ T0) + rng.normal(0, 2.5, (n, 2))).astype(np.float32)
+        r1 = (orc.project(X, K @ orc.compose(T0, M2)) + rng.normal(0, 2.5, (n, 2))).astype(np.float32)
+        for h in range(H):
+            Ts[s, h] = np.hstack([orc.rodrigues_vec_to_mat(np.array([0.004, -0.02, 0.003]) + rng.normal(0, 0.002, 3)),
+                                  (T0[:, 3] + rng.normal(0, 0.02, 3))[:, None]])
+        Ts[s, 1, 0, 1], Ts[s, 2, 1, 3], Ts[s, 3, 2, 0], Ts[s, 4, 0, 3], Ts[s, 5, 1, 0] = np.nan, np.inf, -np.inf, np.nan, -0.0
+        Ts[s, 6] = np.nan                                              # what a degenerate sample produces
+        Ts[s, 299, 2, 3] = np.inf
+        status[s, :8] = 1
+        if n > 7:
+            X[7] = -np.linalg.solve(Ts[s, 0, :, :3], Ts[s, 0, :, 3]) + Ts[s, 0, :, :3].T @ np.array([0.3, 0.1, 0.0])
+        Xs[s, :n], xy1[s, :n] = X, np.hstack([l1, r1])
+        with np.errstate(all="ignore"):
+            for h in range(H):
+                if status[s, h] and n:
+                    want[s, h] = orc.consensus_match(K, Ts[s, h], M2, X, l1.astype(np.float64), r1.astype(np.float64), 2).sum()
+    args = (K, M2, dev(Xs), dev(xy1), dev(np.array(sizes, np.int32)), dev(Ts), dev(status), 4.0)
+    cnt, _ = ops.score_hypotheses(*args)                               # >= 256 hypotheses, no mask: lane per hypothesis
+    cnt_w, _ = ops.score_hypotheses(*args, want_mask=True)             # mask path: wavefront per hypothesis
+    assert np.array_equal(cnt.cpu().numpy(), want)
+    assert np.array_equal(cnt_w.cpu().numpy(), want)
+    assert want[-1].max() > 100 and (want[:, 6] == 0).all()
+
+
 def test_device_sample_stream_equals_numpy():
     """slam_randint_draws against np.random.seed / np.random.randint itself: bounds at and around powers of two (the
     rejection rate's extremes), bound 1 (numpy consumes nothing), ranges that start mid-stream and straddle the 624-word
