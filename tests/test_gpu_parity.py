@@ -57,6 +57,26 @@ def test_crosscheck_match_random_full_bytes():
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("shape", [(70000, 6000), (6000, 70000)])
+def test_crosscheck_match_row_indices_beyond_16_bits(shape):
+    """Row indices above 65535 on either side of the packed keys (distance << 20 | row; SLAM_MAX_ROWS = 2^20): near
+    duplicates planted at the far end of the long side must come back with their own indices."""
+    rng = np.random.default_rng(shape[0])
+    nq, nt = shape
+    q = rng.integers(0, 256, (nq, 61), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 61), dtype=np.uint8)
+    k = np.arange(200)
+    t[nt - 1 - k] = q[nq - 1 - 3 * k]                       # exact copies, far ends of both images
+    t[nt - 1 - k, 5] ^= 0x10                                # ... one cell apart
+    want = c_oracle.match_crosscheck_w64(c_oracle.pad64(q), c_oracle.pad64(t), orc.NORM_HAMMING2)
+    got = gpu_crosscheck(q, t, orc.NORM_HAMMING2)
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+    hit = {(int(a), int(b)) for a, b, d in zip(*got) if d == 1}
+    assert {(nq - 1 - 3 * int(i), nt - 1 - int(i)) for i in k} <= hit
+    assert max(max(got[0]), max(got[1])) > 65535
+
+
 def test_match_empty_inputs():
     q = np.zeros((0, 61), np.uint8)
     t = np.random.default_rng(0).integers(0, 256, (10, 61), dtype=np.uint8)
