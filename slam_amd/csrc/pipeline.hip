@@ -49,7 +49,7 @@ struct Carver {
 struct Buffers {
     // device
     uint32_t *stereo_key, *temporal_key;
-    int32_t *prob_q, *prob_t, *pair_f0, *pair_f1, *tcount, *aux;
+    int32_t *setup, *prob_q, *prob_t, *pair_f0, *pair_f1, *tcount, *aux;
     float *xy0, *xy1;
     double *X;
     int32_t *sample0, *produced0, *cnt0, *best_idx, *best_cnt;
@@ -67,6 +67,7 @@ struct Buffers {
     int32_t *h_seg_of[2], *h_beginR[2], *h_cntR[2], *h_best_idxR[2];
     uint8_t *h_status0, *h_statusR[2], *h_refit_status;
     int D0, RB;
+    size_t setup_len;
     // temporal keys of a chunk with F frames start right after its F stereo key rows
     uint32_t *temporal_key_at(int F, int N) const { return stereo_key + (size_t)F * N; }
 };
@@ -79,10 +80,14 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     b.RB = (int)(HYP_BUDGET / ROUND_QUANTUM);
     b.stereo_key = d.take<uint32_t>((Fs + Ps) * N);   // one key array: F stereo problems, then P temporal ones
     b.temporal_key = b.stereo_key ? b.stereo_key + Fs * N : nullptr;
-    b.prob_q = d.take<int32_t>(Fs + Ps);
-    b.prob_t = d.take<int32_t>(Fs + Ps);
-    b.pair_f0 = d.take<int32_t>(Ps);
-    b.pair_f1 = d.take<int32_t>(Ps);
+    // per-call set-up arrays in ONE block, uploaded with one copy: problem lists, pair frames, pair seeds
+    b.setup_len = 2 * (Fs + Ps) + 3 * Ps;
+    b.setup = d.take<int32_t>(b.setup_len);
+    b.prob_q = b.setup;
+    b.prob_t = b.setup ? b.setup + (Fs + Ps) : nullptr;
+    b.pair_f0 = b.setup ? b.setup + 2 * (Fs + Ps) : nullptr;
+    b.pair_f1 = b.setup ? b.pair_f0 + Ps : nullptr;
+    b.seed = b.setup ? (uint32_t *)(b.pair_f1 + Ps) : nullptr;
     b.tcount = d.take<int32_t>(Ps);
     b.aux = d.take<int32_t>(2 * Ps);
     b.xy0 = d.take<float>(Ps * N * 4);
@@ -100,7 +105,6 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     b.mask = d.take<uint64_t>(Ps * (N / 64));
     b.refit_pose = d.take<double>(Ps * 12);
     b.refit_status = d.take<uint8_t>(Ps);
-    b.seed = d.take<uint32_t>(Ps);
     for (int k = 0; k < 2; ++k) {
         b.seg_of[k] = d.take<int32_t>(b.RB);
         b.beginR[k] = d.take<int32_t>(b.RB);
@@ -111,7 +115,7 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
         b.best_idxR[k] = d.take<int32_t>(b.RB);
     }
 
-    b.h_prob = h.take<int32_t>(2 * (Fs + Ps));
+    b.h_prob = h.take<int32_t>(2 * (Fs + Ps) + 3 * Ps);   // mirrors `setup`
     b.h_tcount = h.take<int32_t>(Ps);
     b.h_aux = h.take<int32_t>(2 * Ps);
     b.h_produced0 = h.take<int32_t>(Ps);
@@ -302,19 +306,25 @@ struct Lane {
         const int N = sh.N, D0 = b.D0;
         int rc = ensure_events();
         if (rc) return rc;
-        for (int f = 0; f < F; ++f) {
-            b.h_prob[f] = 2 * f;
-            b.h_prob[F + P + f] = 2 * f + 1;
+        // The set-up block is laid out for the lane's capacity, so this chunk's arrays sit at the capacity's offsets in
+        // the pinned mirror too; one copy uploads the block.
+        {
+            int32_t *hq = b.h_prob, *ht = b.h_prob + (b.prob_t - b.setup);
+            int32_t *h_f0 = b.h_prob + (b.pair_f0 - b.setup), *h_f1 = b.h_prob + (b.pair_f1 - b.setup);
+            uint32_t *h_seed = (uint32_t *)(b.h_prob + ((int32_t *)b.seed - b.setup));
+            for (int f = 0; f < F; ++f) {
+                hq[f] = 2 * f;              // stereo problems: left image of frame f ...
+                ht[f] = 2 * f + 1;          // ... against its right image
+            }
+            for (int p = 0; p < P; ++p) {
+                hq[F + p] = 2 * f0[p];      // temporal problems: left images of the pair's two frames
+                ht[F + p] = 2 * f1[p];
+                h_f0[p] = f0[p];
+                h_f1[p] = f1[p];
+                h_seed[p] = seed[p];
+            }
+            SLAM_HIP_CHECK(hipMemcpyAsync(b.setup, b.h_prob, sizeof(int32_t) * b.setup_len, hipMemcpyHostToDevice, st));
         }
-        for (int p = 0; p < P; ++p) {
-            b.h_prob[F + p] = 2 * f0[p];
-            b.h_prob[F + P + F + p] = 2 * f1[p];
-        }
-        SLAM_HIP_CHECK(hipMemcpyAsync(b.prob_q, b.h_prob, sizeof(int32_t) * (F + P), hipMemcpyHostToDevice, st));
-        SLAM_HIP_CHECK(hipMemcpyAsync(b.prob_t, b.h_prob + F + P, sizeof(int32_t) * (F + P), hipMemcpyHostToDevice, st));
-        SLAM_HIP_CHECK(hipMemcpyAsync(b.pair_f0, f0.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
-        SLAM_HIP_CHECK(hipMemcpyAsync(b.pair_f1, f1.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
-        SLAM_HIP_CHECK(hipMemcpyAsync(b.seed, seed, sizeof(uint32_t) * P, hipMemcpyHostToDevice, st));
         SLAM_HIP_CHECK(hipEventRecord(ev[0], st));
         // ---- 1. matching: F stereo + P temporal problems, ONE launch over the contiguous key array ----
         rc = slam_match_hamming_batched(d_desc, d_count, N, b.prob_q, b.prob_t, F + P, sh.norm, SLAM_MATCH_CROSSCHECK,
