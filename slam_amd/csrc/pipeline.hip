@@ -364,7 +364,7 @@ struct Lane {
         double t_h0 = now_ms();
         rs.assign(P, RansacReplay());
         active.clear();
-        parallel_for(P, 256, [&](int a, int e) {         // pairs are independent: replay them on all host cores
+        parallel_for(P, 64, [&](int a, int e) {          // pairs are independent: replay them on all host cores
             for (int p = a; p < e; ++p) {
                 RansacReplay &r = rs[p];
                 const int n = b.h_tcount[p];
