@@ -64,7 +64,7 @@ __device__ __forceinline__ int within_fast(const double *P, double x, double y, 
     double r = __builtin_amdgcn_rcp(hz);
     r = fma(r, fma(-hz, r, 1.0), r);
     r = fma(r, fma(-hz, r, 1.0), r);
-    const double dx = hx * r - u, dy = hy * r - v;
+    const double dx = fma(hx, r, -u), dy = fma(hy, r, -v);      // fused: this path only classifies against the band
     const double q = fma(dx, dx, dy * dy);
     return q < lo ? 1 : (q > hi ? 0 : -1);
 }
@@ -85,8 +85,7 @@ __device__ __forceinline__ int within_fast_rect(const double *Pl, double pr3, do
     double r = __builtin_amdgcn_rcp(hz);
     r = fma(r, fma(-hz, r, 1.0), r);
     r = fma(r, fma(-hz, r, 1.0), r);
-    const double py = hy * r;
-    const double dxl = hxl * r - ul, dyl = py - vl, dxr = hxr * r - ur, dyr = py - vr;
+    const double dxl = fma(hxl, r, -ul), dyl = fma(hy, r, -vl), dxr = fma(hxr, r, -ur), dyr = fma(hy, r, -vr);
     const double ql = fma(dxl, dxl, dyl * dyl), qr = fma(dxr, dxr, dyr * dyr);
     if (ql > hi || qr > hi) return 0;
     return (ql < lo && qr < lo) ? 1 : -1;
