@@ -649,3 +649,35 @@ def find_loop_cand_by_consensus(mahalanobis_dist_cand_movie_ind, mahalanobis_dis
             f0, f1 = _features_of(sup[:, :2], xy[1 + c]), _features_of(sup[:, 2:], xy[0])
             passed.append([mahalanobis_dist_cand_pg_ind[c], create_little_tracks(f0, f1, cands[c], cur_frame_movie_ind)])
     return passed
+
+
+def find_loop_cands_by_consensus_batch(cand_movie_ind_lists, cand_pg_ind_lists, cur_frame_movie_inds, threshold, seeds=None):
+    """find_loop_cand_by_consensus (:1118-1146) for MANY current frames in one device pass: what the key-frame loop of
+    PoseGraph.loop_closure (PoseGraph.py:463-472 -> :386-410) asks for one frame at a time.  Every frame that occurs,
+    as current frame or as candidate, is detected and stereo-matched once; all (candidate, current) pairs go through
+    one slam_track_pairs call.  Returns one `[[pg_index, tracks], ...]` list per current frame, each equal to what
+    find_loop_cand_by_consensus returns for that frame with the same per-pair seeds (`seeds`: one per pair, in the
+    order current frame by current frame, candidate by candidate)."""
+    curs = [int(c) for c in cur_frame_movie_inds]
+    lists = [[int(c) for c in cl] for cl in cand_movie_ind_lists]
+    if len(lists) != len(curs) or len(cand_pg_ind_lists) != len(curs):
+        raise ValueError("one candidate list and one pose-graph index list per current frame")
+    frames = sorted(set(curs).union(*map(set, lists))) if curs else []
+    pos = {f: i for i, f in enumerate(frames)}
+    pair_f0 = np.array([pos[c] for cl in lists for c in cl], np.int32)                   # candidate = "frame 0" (:1128-1134)
+    pair_f1 = np.array([pos[cur] for cur, cl in zip(curs, lists) for _ in cl], np.int32)  # current frame = "frame 1"
+    out = [[] for _ in curs]
+    if len(pair_f0) == 0:
+        return out
+    res, xy, kp = track_pairs_arrays(np.array(frames), pair_f0, pair_f1, seeds)
+    _check_pairs(res)
+    p = 0
+    for k, (cur, cl) in enumerate(zip(curs, lists)):
+        for c, cand in enumerate(cl):
+            T = int(res.stats[p, 0])
+            if 100 * int(res.stats[p, 1]) / T > threshold:                               # strict (:1141)
+                sup = kp[p, :T][res.mask[p, :T]]
+                f0, f1 = _features_of(sup[:, :2], xy[pos[cand]]), _features_of(sup[:, 2:], xy[pos[cur]])
+                out[k].append([cand_pg_ind_lists[k][c], create_little_tracks(f0, f1, cand, cur)])
+            p += 1
+    return out

@@ -113,3 +113,27 @@ def test_fewer_than_six_supporters_gives_no_pose(golden_more):
     assert T is None and bool(g["few_T_is_none"])
     assert np.array_equal(mask, g["few_mask"])
     assert np.random.randint(0, 1 << 30) == int(g["few_next_rand"])
+
+
+def test_loop_candidates_of_many_current_frames_in_one_pass(golden, movie):
+    """Row N2: the key-frame loop of PoseGraph.loop_closure hands one current frame at a time; the batch entry point
+    takes them all, shares detections and stereo matches between them, and returns what the per-frame calls return."""
+    curs, cands, pgs = [4, 5, 7, 6], [[3, 0], [1], [], [2, 5, 0]], [[30, 0], [10], [], [20, 50, 0]]
+    seeds = 100 + np.arange(6)
+
+    def summary(out):
+        return [(pg, [(list(t.get_frames_ids()), t.get_left_locations_in_all_frames(), t.get_right_locations_in_all_frames())
+                      for t in trs]) for pg, trs in out]
+
+    for thr in (50.0, 96.5, 100.0):
+        got = U.find_loop_cands_by_consensus_batch(cands, pgs, curs, thr, seeds=seeds)
+        assert len(got) == len(curs) and got[2] == []
+        p = 0
+        for k, cur in enumerate(curs):
+            want = U.find_loop_cand_by_consensus(cands[k], pgs[k], cur, thr, seeds=seeds[p:p + len(cands[k])])
+            assert summary(got[k]) == summary(want)
+            p += len(cands[k])
+    assert sum(len(g) for g in U.find_loop_cands_by_consensus_batch(cands, pgs, curs, 50.0, seeds=seeds)) == 6
+    assert U.find_loop_cands_by_consensus_batch([], [], [], 50.0) == []
+    with pytest.raises(ValueError):
+        U.find_loop_cands_by_consensus_batch([[1]], [[1], [2]], [3], 50.0)
