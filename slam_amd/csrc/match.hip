@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "kernels.h"
 
 namespace {
 
@@ -61,6 +62,7 @@ struct MatchBatch {
     const int *count;         // batched: rows per image
     const int *prob_a;        // batched: A image per problem
     const int *prob_b;        // batched: B image per problem
+    const int *order;         // batched, optional: the problem the k-th group of A tiles works on (a permutation)
     const uint4 *a_ptr;       // single problem
     const uint4 *b_ptr;
     int na, nb;               // single problem sizes
@@ -137,7 +139,10 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
     const unsigned logical = (blockIdx.x % 8u) * (nblk / 8u) + blockIdx.x / 8u;
     const unsigned total = (unsigned)mb.tiles_per_prob * (unsigned)mb.n_prob;
     if (logical >= total) return;
-    const int p = logical / mb.tiles_per_prob;
+    // `order` lets the caller put problems that share an image next to each other in launch order (same XCD, same
+    // time), so the image is fetched from HBM once; results do not depend on it
+    const int slot = logical / mb.tiles_per_prob;
+    const int p = mb.order ? mb.order[slot] : slot;
     const int tile_a = logical % mb.tiles_per_prob;
     const int split = blockIdx.y;
 
@@ -448,7 +453,13 @@ extern "C" int slam_match_hamming(const uint8_t *d_query, int n_query, const uin
 extern "C" int slam_match_hamming_batched(const uint8_t *d_desc, const int32_t *d_count, int n_max,
                                           const int32_t *d_prob_query, const int32_t *d_prob_train, int n_prob,
                                           int norm, int mode, uint32_t *d_key1, uint32_t *d_key2, void *stream) {
-    hipStream_t st = (hipStream_t)stream;
+    return slam_launch_match_batched(d_desc, d_count, n_max, d_prob_query, d_prob_train, nullptr, n_prob, norm, mode,
+                                     d_key1, d_key2, (hipStream_t)stream);
+}
+
+int slam_launch_match_batched(const uint8_t *d_desc, const int32_t *d_count, int n_max, const int32_t *d_prob_query,
+                              const int32_t *d_prob_train, const int32_t *d_order, int n_prob, int norm, int mode,
+                              uint32_t *d_key1, uint32_t *d_key2, hipStream_t st) {
     SLAM_REQUIRE(norm == SLAM_NORM_HAMMING || norm == SLAM_NORM_HAMMING2, "slam_match_hamming_batched: norm %d", norm);
     SLAM_REQUIRE(mode == SLAM_MATCH_CROSSCHECK || mode == SLAM_MATCH_KNN2, "slam_match_hamming_batched: mode %d", mode);
     SLAM_REQUIRE(n_max > 0 && n_max < SLAM_MAX_ROWS && n_prob >= 0, "slam_match_hamming_batched: bad sizes");
@@ -464,6 +475,7 @@ extern "C" int slam_match_hamming_batched(const uint8_t *d_desc, const int32_t *
     mb.count = d_count;
     mb.prob_a = cross ? d_prob_train : d_prob_query;
     mb.prob_b = cross ? d_prob_query : d_prob_train;
+    mb.order = d_order;
     mb.n_max = n_max;
     mb.n_prob = n_prob;
     mb.tiles_per_prob = slam_div_up(n_max, TILE_A);

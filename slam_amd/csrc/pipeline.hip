@@ -25,9 +25,6 @@
 #include "kernels.h"
 #include "ransac_host.h"
 
-extern "C" int slam_match_hamming_batched(const uint8_t *, const int32_t *, int, const int32_t *, const int32_t *, int,
-                                          int, int, uint32_t *, uint32_t *, void *);
-
 namespace {
 
 constexpr long HYP_BUDGET = 1 << 20;       // hypotheses per sub-batch of a later RANSAC round (pose buffer: 100 MB)
@@ -49,7 +46,7 @@ struct Carver {
 struct Buffers {
     // device
     uint32_t *stereo_key, *temporal_key;
-    int32_t *setup, *prob_q, *prob_t, *pair_f0, *pair_f1, *tcount, *aux;
+    int32_t *setup, *prob_q, *prob_t, *pair_f0, *pair_f1, *order, *tcount, *aux;
     float *xy0, *xy1;
     double *X;
     int32_t *sample0, *produced0, *cnt0, *best_idx, *best_cnt;
@@ -81,13 +78,14 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     b.stereo_key = d.take<uint32_t>((Fs + Ps) * N);   // one key array: F stereo problems, then P temporal ones
     b.temporal_key = b.stereo_key ? b.stereo_key + Fs * N : nullptr;
     // per-call set-up arrays in ONE block, uploaded with one copy: problem lists, pair frames, pair seeds
-    b.setup_len = 2 * (Fs + Ps) + 3 * Ps;
+    b.setup_len = 3 * (Fs + Ps) + 3 * Ps;
     b.setup = d.take<int32_t>(b.setup_len);
     b.prob_q = b.setup;
     b.prob_t = b.setup ? b.setup + (Fs + Ps) : nullptr;
     b.pair_f0 = b.setup ? b.setup + 2 * (Fs + Ps) : nullptr;
     b.pair_f1 = b.setup ? b.pair_f0 + Ps : nullptr;
     b.seed = b.setup ? (uint32_t *)(b.pair_f1 + Ps) : nullptr;
+    b.order = b.setup ? b.pair_f1 + 2 * Ps : nullptr;
     b.tcount = d.take<int32_t>(Ps);
     b.aux = d.take<int32_t>(2 * Ps);
     b.xy0 = d.take<float>(Ps * N * 4);
@@ -115,7 +113,7 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
         b.best_idxR[k] = d.take<int32_t>(b.RB);
     }
 
-    b.h_prob = h.take<int32_t>(2 * (Fs + Ps) + 3 * Ps);   // mirrors `setup`
+    b.h_prob = h.take<int32_t>(3 * (Fs + Ps) + 3 * Ps);   // mirrors `setup`
     b.h_tcount = h.take<int32_t>(Ps);
     b.h_aux = h.take<int32_t>(2 * Ps);
     b.h_produced0 = h.take<int32_t>(Ps);
@@ -267,7 +265,7 @@ struct Lane {
     const uint8_t *d_desc = nullptr;
     const float *d_xy = nullptr;
     const int32_t *d_count = nullptr;
-    std::vector<int32_t> f0, f1;
+    std::vector<int32_t> f0, f1, order_start, order_fill;
     const uint32_t *seed = nullptr;
     std::vector<RansacReplay> rs;
     std::vector<int> active;
@@ -323,12 +321,26 @@ struct Lane {
                 h_f1[p] = f1[p];
                 h_seed[p] = seed[p];
             }
+            // Launch order of the problems: frame by frame, a frame's stereo problem and then the temporal problems
+            // whose later frame it is.  A left image is an operand of up to three problems (stereo f, temporal f-1 -> f
+            // and f -> f+1); next to each other they run on one XCD at about the same time and the image comes from HBM
+            // once instead of three times.  Counting sort, O(F + P).
+            int32_t *h_order = b.h_prob + (b.order - b.setup);
+            order_start.assign(F + 1, 0);
+            for (int p = 0; p < P; ++p) ++order_start[std::max(f0[p], f1[p]) + 1];
+            for (int f = 0; f < F; ++f) order_start[f + 1] += order_start[f] + 1;          // + the frame's stereo problem
+            for (int f = 0; f < F; ++f) h_order[order_start[f]] = f;
+            order_fill.assign(order_start.begin(), order_start.end() - 1);
+            for (int p = 0; p < P; ++p) {
+                const int f = std::max(f0[p], f1[p]);
+                h_order[++order_fill[f]] = F + p;
+            }
             SLAM_HIP_CHECK(hipMemcpyAsync(b.setup, b.h_prob, sizeof(int32_t) * b.setup_len, hipMemcpyHostToDevice, st));
         }
         SLAM_HIP_CHECK(hipEventRecord(ev[0], st));
         // ---- 1. matching: F stereo + P temporal problems, ONE launch over the contiguous key array ----
-        rc = slam_match_hamming_batched(d_desc, d_count, N, b.prob_q, b.prob_t, F + P, sh.norm, SLAM_MATCH_CROSSCHECK,
-                                        b.stereo_key, nullptr, st);
+        rc = slam_launch_match_batched(d_desc, d_count, N, b.prob_q, b.prob_t, b.order, F + P, sh.norm,
+                                       SLAM_MATCH_CROSSCHECK, b.stereo_key, nullptr, st);
         if (rc) return rc;
         SLAM_HIP_CHECK(hipEventRecord(ev[1], st));
         // ---- 2. join, 3. triangulate ----
