@@ -129,9 +129,13 @@ __device__ __forceinline__ void top2_insert(unsigned &m1, unsigned &m2, unsigned
 
 // FUSED: cross-check scatter straight from the all-pairs kernel (nsplit == 1).
 // TOP2: keep the second best too (kNN mode); cross-check needs only the nearest row.
-template <bool NORM2, bool FUSED, bool TOP2>
+// RW = A rows per lane: ROWS (4) where the grid fills the chip, 2 for a batch of few problems (twice as many
+// wavefronts for the same work, see launch_allpairs).
+template <bool NORM2, bool FUSED, bool TOP2, int RW>
 __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
     __shared__ uint4 tile[2][TILE_B * 4];
+    constexpr int ROWS = RW;                 // shadows the file-scope default inside the kernel
+    constexpr int TILE_A = ROWS * BLOCK;
 
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
     // range of logical blocks; the A tiles of one problem then share one L2 for their B rows.
@@ -372,22 +376,40 @@ __global__ void unpack_keys_kernel(const unsigned *key, int n, int *index, int *
     distance[i] = k == NONE ? INT32_MAX : (int)(k >> SLAM_KEY_SHIFT);
 }
 
-template <bool FUSED>
-void launch_allpairs(const MatchBatch &mb, int norm, hipStream_t st) {
+// Workgroups the chip holds at once: 256 CUs x 3 (139 VGPRs = 3 wavefronts per SIMD, 4 wavefronts per workgroup).
+constexpr unsigned CHIP_WORKGROUPS = 768;
+constexpr int ROWS_SMALL = 2;
+
+template <bool FUSED, int RW>
+void launch_allpairs_rows(MatchBatch mb, int a_rows, int norm, hipStream_t st) {
+    mb.tiles_per_prob = slam_div_up(a_rows, RW * BLOCK);
     const unsigned total = (unsigned)mb.tiles_per_prob * (unsigned)mb.n_prob;
     dim3 grid((total + 7u) / 8u * 8u, mb.nsplit);
     const bool top2 = mb.out2 != nullptr;
     if (norm == SLAM_NORM_HAMMING2) {
         if (top2)
-            hipLaunchKernelGGL((allpairs_top2_kernel<true, false, true>), grid, dim3(BLOCK), 0, st, mb);
+            hipLaunchKernelGGL((allpairs_top2_kernel<true, false, true, RW>), grid, dim3(BLOCK), 0, st, mb);
         else
-            hipLaunchKernelGGL((allpairs_top2_kernel<true, FUSED, false>), grid, dim3(BLOCK), 0, st, mb);
+            hipLaunchKernelGGL((allpairs_top2_kernel<true, FUSED, false, RW>), grid, dim3(BLOCK), 0, st, mb);
     } else {
         if (top2)
-            hipLaunchKernelGGL((allpairs_top2_kernel<false, false, true>), grid, dim3(BLOCK), 0, st, mb);
+            hipLaunchKernelGGL((allpairs_top2_kernel<false, false, true, RW>), grid, dim3(BLOCK), 0, st, mb);
         else
-            hipLaunchKernelGGL((allpairs_top2_kernel<false, FUSED, false>), grid, dim3(BLOCK), 0, st, mb);
+            hipLaunchKernelGGL((allpairs_top2_kernel<false, FUSED, false, RW>), grid, dim3(BLOCK), 0, st, mb);
     }
+}
+
+// a_rows = A rows per problem slot (the tile grid covers them).  A batch of few problems (the stress configuration:
+// 59 problems of 8k x 8k rows = 472 workgroups at 4 rows per lane) leaves a third of the chip's wavefront slots empty;
+// it runs with 2 rows per lane instead: twice the wavefronts for the same distances.  At full load 4 rows per lane is
+// 9 % faster (DESIGN.md tile sweep), so that stays the choice whenever the grid fills the chip.
+template <bool FUSED>
+void launch_allpairs(const MatchBatch &mb, int a_rows, int norm, hipStream_t st) {
+    const unsigned total4 = (unsigned)slam_div_up(a_rows, TILE_A) * (unsigned)mb.n_prob * (unsigned)mb.nsplit;
+    if (ROWS > ROWS_SMALL && total4 < CHIP_WORKGROUPS)
+        launch_allpairs_rows<FUSED, ROWS_SMALL>(mb, a_rows, norm, st);
+    else
+        launch_allpairs_rows<FUSED, ROWS>(mb, a_rows, norm, st);
 }
 
 int pick_nsplit(int na, int nb) {
@@ -430,7 +452,6 @@ extern "C" int slam_match_hamming(const uint8_t *d_query, int n_query, const uin
     mb.na = cross ? n_train : n_query;
     mb.nb = cross ? n_query : n_train;
     mb.n_prob = 1;
-    mb.tiles_per_prob = slam_div_up(mb.na, TILE_A);
     mb.nsplit = pick_nsplit(mb.na, mb.nb);
     const size_t need = 2 * (size_t)mb.nsplit * mb.na * sizeof(unsigned);
     if (workspace_bytes < need || !d_workspace) {
@@ -442,7 +463,7 @@ extern "C" int slam_match_hamming(const uint8_t *d_query, int n_query, const uin
     mb.out1 = part1;
     mb.out2 = cross ? nullptr : part2;
     mb.out_stride = 0;
-    launch_allpairs<false>(mb, norm, st);
+    launch_allpairs_rows<false, ROWS>(mb, mb.na, norm, st);      // B is split until the grid fills the chip (pick_nsplit)
     SLAM_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(merge_splits_kernel, dim3(slam_div_up(mb.na, 256)), dim3(256), 0, st, part1, mb.out2, mb.na,
                        mb.nsplit, cross ? 1 : 0, d_key1, d_key2);
@@ -478,15 +499,14 @@ int slam_launch_match_batched(const uint8_t *d_desc, const int32_t *d_count, int
     mb.order = d_order;
     mb.n_max = n_max;
     mb.n_prob = n_prob;
-    mb.tiles_per_prob = slam_div_up(n_max, TILE_A);
     mb.nsplit = 1;
     mb.out1 = d_key1;
     mb.out2 = cross ? nullptr : d_key2;
     mb.out_stride = n_max;
     if (cross)
-        launch_allpairs<true>(mb, norm, st);
+        launch_allpairs<true>(mb, n_max, norm, st);
     else
-        launch_allpairs<false>(mb, norm, st);   // nsplit == 1: partial slot 0 is the final answer
+        launch_allpairs<false>(mb, n_max, norm, st);   // nsplit == 1: partial slot 0 is the final answer
     SLAM_HIP_CHECK(hipGetLastError());
     return SLAM_OK;
 }
