@@ -163,6 +163,40 @@ def _small_sequence(n_frames=5, n_features=300, seed=3):
     return seq, desc, xy, count
 
 
+@pytest.mark.parametrize("mode", ["crosscheck", "knn2"])
+def test_batched_matcher_rows_per_lane_variants_agree(mode):
+    """The batched matcher runs 4 rows per lane when the grid fills the chip and 2 rows per lane for a small batch
+    (launch_allpairs).  The same six problems go through both: alone (2 rows) and repeated 70 times in one batch of 420
+    problems x 2 tiles (4 rows); keys must be identical, and equal to the single-problem entry point's."""
+    rng = np.random.default_rng(17)
+    n_max = 2048
+    counts = np.array([1970, 2048, 1, 1025, 700, 0, 1500, 64], np.int32)
+    desc = np.zeros((len(counts), n_max, 64), np.uint8)
+    for i, n in enumerate(counts):
+        desc[i, :n, :61] = rng.integers(0, 6, (n, 61), dtype=np.uint8)      # few byte values: many ties
+    desc[1, :900, :61] = desc[0, :900, :61]
+    pq = np.array([0, 1, 2, 3, 6, 5], np.int32)
+    pt = np.array([1, 0, 3, 4, 7, 6], np.int32)
+    m = _lib.SLAM_MATCH_CROSSCHECK if mode == "crosscheck" else _lib.SLAM_MATCH_KNN2
+    d_desc, d_count = dev(desc), dev(counts)
+    small = ops.match_keys_batched(d_desc, d_count, dev(pq), dev(pt), mode=m)
+    big = ops.match_keys_batched(d_desc, d_count, dev(np.tile(pq, 70)), dev(np.tile(pt, 70)), mode=m)
+    for a, b in zip(small, big):
+        if a is None:
+            assert b is None
+            continue
+        a, b = a.cpu().numpy(), b.cpu().numpy().reshape(70, len(pq), n_max)
+        assert (b == a[None]).all()
+    for k in range(len(pq)):
+        nq, nt = counts[pq[k]], counts[pt[k]]
+        if nq == 0:
+            continue
+        one = ops.match_keys(dev(desc[pq[k], :nq]), dev(desc[pt[k], :nt]), orc.NORM_HAMMING2, m)
+        for a, b in zip(small, one):
+            if a is not None:
+                assert np.array_equal(a.cpu().numpy()[k, :nq], b.cpu().numpy())
+
+
 def test_batched_match_and_join_bit_exact():
     seq, desc, xy, count = _small_sequence()
     F, _, n_max, _ = desc.shape
