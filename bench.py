@@ -118,6 +118,8 @@ def main():
     trk = pipeline.ShardTracker(F, P, n_max, cfg, n_chunks=args.chunks, taper=args.taper)
 
     n_compose = F_total - 1                           # rank 0 composes the first movie's trajectory
+    rel_buf = np.empty((n_compose + 1, 3, 4))
+    rel_buf[0] = np.eye(3, 4)                         # the first camera (M1)
 
     def step():
         res = trk.run(d_desc, d_xy, d_count, f0, f1, seeds, unpack_mask=False)
@@ -126,8 +128,11 @@ def main():
         glob = None
         if rank == 0:
             # host-side composition (utils/utills.py:749-757); pairs with no pose keep the previous camera
-            rel = np.where(np.isfinite(rel_all).all(axis=(1, 2), keepdims=True), rel_all, np.eye(3, 4)[None])
-            glob = pipeline.compose_global(np.concatenate([np.eye(3, 4)[None], rel[:n_compose]]))
+            rel_buf[1:] = rel_all[:n_compose]
+            bad = ~np.isfinite(rel_buf.reshape(n_compose + 1, 12)).all(axis=1)
+            if bad.any():
+                rel_buf[bad] = np.eye(3, 4)
+            glob = pipeline.compose_global(rel_buf)
         return res, glob
 
     def fence():
