@@ -12,8 +12,8 @@ Covers the entry points the first batch leaves out (SURVEY 8a rows 2, 10, 11, 12
   * apply_full_consensus_match  (:1103-1115) on a non-consecutive pair;
   * find_loop_cand_by_consensus + create_little_tracks  (:1118-1167): candidates that pass and that fail the
     strict inlier-percentage threshold, all drawing from ONE global random stream in candidate order;
-  * online_est_pnp_ransac on a set with fewer than 6 supporters (:558-559): pose None, mask still returned,
-    and on a set where EVERY draw is degenerate up to the retry bound is not recorded (the reference loops forever).
+  * online_est_pnp_ransac on a set with fewer than 6 supporters (:558-559): pose None, mask still returned.
+    (A set on which EVERY solve fails is not recorded: the reference's retry loop, :506-507, never returns on it.)
 Only inputs and outputs (data) are stored.
 """
 import contextlib
