@@ -66,6 +66,18 @@ int slam_match_hamming(const uint8_t *d_query, int n_query, const uint8_t *d_tra
                        int mode, uint32_t *d_key1, uint32_t *d_key2, void *d_workspace, size_t workspace_bytes,
                        void *stream);
 
+/* slam_match_hamming for callers that cannot allocate device memory and have no workspace to bring: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference (which
+ * never touches a GPU); it exists only for those callers.  Same inputs, outputs and results as slam_match_hamming; the
+ * per-split partial lists live in a static device array inside the library (4 MiB per GPU, held until the process
+ * ends) instead of a caller workspace, so n_query and n_train must each be <= SLAM_MATCH_NOALLOC_MAX_ROWS (larger
+ * sizes return SLAM_E_INVALID and launch nothing).  The call allocates and frees nothing (no hipMalloc / hipFree, no
+ * allocating library routine).  The device that owns `stream` must be current.  All calls on one GPU share that
+ * GPU's array: calls that overlap on one GPU (different streams or threads) race; serialise them. */
+#define SLAM_MATCH_NOALLOC_MAX_ROWS 8192
+int slam_match_hamming_noalloc(const uint8_t *d_query, int n_query, const uint8_t *d_train, int n_train, int norm,
+                               int mode, uint32_t *d_key1, uint32_t *d_key2, void *stream);
+
 /* Batched form: one launch for many image pairs.  Image k holds h/d_count[k] rows at
  * d_desc + k * n_max * 64.  Problem p matches query image prob_query[p] against train image
  * prob_train[p]; results go to d_key1 + p * n_max (and d_key2 + p * n_max for KNN2).

@@ -17,6 +17,7 @@ SLAM_MATCH_CROSSCHECK = 0
 SLAM_MATCH_KNN2 = 1
 SLAM_KEY_SHIFT = 20
 SLAM_KEY_NONE = 0xFFFFFFFF
+SLAM_MATCH_NOALLOC_MAX_ROWS = 8192
 SLAM_OK, SLAM_E_INVALID, SLAM_E_WORKSPACE, SLAM_E_HIP, SLAM_E_EMPTY = 0, -1, -2, -3, -4
 
 SLAM_PAIR_OK, SLAM_PAIR_EMPTY, SLAM_PAIR_FEW, SLAM_PAIR_DRAW_CAP = 1, 2, 4, 8
@@ -50,6 +51,7 @@ SIGNATURES = {
     "slam_match_workspace_bytes": (c_size_t, [c_int, c_int]),
     "slam_match_hamming": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                    c_size_t, c_void_p]),
+    "slam_match_hamming_noalloc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "slam_match_hamming_batched": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_void_p, c_void_p, c_void_p]),
     "slam_unpack_keys": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -24,6 +24,7 @@
 //   - cross-check (OpenCV batchDistance(crosscheck=true)): A = train rows; the nearest query of
 //     every train row is scattered with atomicMin on key (distance << 20 | train row) into the
 //     query's slot.  min is order independent, so the result is deterministic.
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -427,19 +428,13 @@ extern "C" size_t slam_match_workspace_bytes(int n_query, int n_train) {
     return 2 * 64 * n * sizeof(unsigned) + 256;
 }
 
-extern "C" int slam_match_hamming(const uint8_t *d_query, int n_query, const uint8_t *d_train, int n_train, int norm,
-                                  int mode, uint32_t *d_key1, uint32_t *d_key2, void *d_workspace,
-                                  size_t workspace_bytes, void *stream) {
-    hipStream_t st = (hipStream_t)stream;
-    SLAM_REQUIRE(norm == SLAM_NORM_HAMMING || norm == SLAM_NORM_HAMMING2, "slam_match_hamming: norm %d unsupported", norm);
-    SLAM_REQUIRE(mode == SLAM_MATCH_CROSSCHECK || mode == SLAM_MATCH_KNN2, "slam_match_hamming: mode %d unsupported", mode);
-    SLAM_REQUIRE(n_query >= 0 && n_train >= 0 && n_query < SLAM_MAX_ROWS && n_train < SLAM_MAX_ROWS,
-                 "slam_match_hamming: row counts %d/%d out of range", n_query, n_train);
-    if (n_query == 0) return SLAM_OK;
-    SLAM_REQUIRE(d_key1 && (mode == SLAM_MATCH_CROSSCHECK || d_key2), "slam_match_hamming: null output");
-    SLAM_REQUIRE(d_query && (d_train || n_train == 0), "slam_match_hamming: null input");
-    SLAM_REQUIRE(((uintptr_t)d_query & 15) == 0 && ((uintptr_t)d_train & 15) == 0,
-                 "slam_match_hamming: descriptor rows must be 16-byte aligned");
+namespace {
+
+// One problem: B split over blockIdx.y into per-split partial lists (`part`, 2 * nsplit * na keys), then merged.
+// Every key of the partial lists the merge reads is written by the all-pairs kernel first (rows < na of every split,
+// empty splits write SLAM_KEY_NONE), so `part` needs no clearing.
+int match_single(const char *who, const uint8_t *d_query, int n_query, const uint8_t *d_train, int n_train, int norm,
+                 int mode, uint32_t *d_key1, uint32_t *d_key2, unsigned *part, size_t part_bytes, hipStream_t st) {
     const bool cross = mode == SLAM_MATCH_CROSSCHECK;
     SLAM_HIP_CHECK(hipMemsetAsync(d_key1, 0xFF, sizeof(uint32_t) * (size_t)n_query, st));
     if (!cross) SLAM_HIP_CHECK(hipMemsetAsync(d_key2, 0xFF, sizeof(uint32_t) * (size_t)n_query, st));
@@ -454,11 +449,11 @@ extern "C" int slam_match_hamming(const uint8_t *d_query, int n_query, const uin
     mb.n_prob = 1;
     mb.nsplit = pick_nsplit(mb.na, mb.nb);
     const size_t need = 2 * (size_t)mb.nsplit * mb.na * sizeof(unsigned);
-    if (workspace_bytes < need || !d_workspace) {
-        slam_set_error("slam_match_hamming: workspace %zu B < %zu B", workspace_bytes, need);
+    if (part_bytes < need || !part) {
+        slam_set_error("%s: workspace %zu B < %zu B", who, part_bytes, need);
         return SLAM_E_WORKSPACE;
     }
-    unsigned *part1 = (unsigned *)d_workspace;
+    unsigned *part1 = part;
     unsigned *part2 = part1 + (size_t)mb.nsplit * mb.na;
     mb.out1 = part1;
     mb.out2 = cross ? nullptr : part2;
@@ -469,6 +464,85 @@ extern "C" int slam_match_hamming(const uint8_t *d_query, int n_query, const uin
                        mb.nsplit, cross ? 1 : 0, d_key1, d_key2);
     SLAM_HIP_CHECK(hipGetLastError());
     return SLAM_OK;
+}
+
+int match_single_check_args(const char *who, const uint8_t *d_query, int n_query, const uint8_t *d_train, int n_train,
+                            int norm, int mode, const uint32_t *d_key1, const uint32_t *d_key2, int max_rows) {
+    SLAM_REQUIRE(norm == SLAM_NORM_HAMMING || norm == SLAM_NORM_HAMMING2, "%s: norm %d unsupported", who, norm);
+    SLAM_REQUIRE(mode == SLAM_MATCH_CROSSCHECK || mode == SLAM_MATCH_KNN2, "%s: mode %d unsupported", who, mode);
+    SLAM_REQUIRE(n_query >= 0 && n_train >= 0 && n_query < max_rows && n_train < max_rows,
+                 "%s: row counts %d/%d out of range (each must be below %d)", who, n_query, n_train, max_rows);
+    if (n_query == 0) return SLAM_OK;
+    SLAM_REQUIRE(d_key1 && (mode == SLAM_MATCH_CROSSCHECK || d_key2), "%s: null output", who);
+    SLAM_REQUIRE(d_query && (d_train || n_train == 0), "%s: null input", who);
+    SLAM_REQUIRE(((uintptr_t)d_query & 15) == 0 && ((uintptr_t)d_train & 15) == 0,
+                 "%s: descriptor rows must be 16-byte aligned", who);
+    return SLAM_OK;
+}
+
+}  // namespace
+
+extern "C" int slam_match_hamming(const uint8_t *d_query, int n_query, const uint8_t *d_train, int n_train, int norm,
+                                  int mode, uint32_t *d_key1, uint32_t *d_key2, void *d_workspace,
+                                  size_t workspace_bytes, void *stream) {
+    const char *who = "slam_match_hamming";
+    const int rc = match_single_check_args(who, d_query, n_query, d_train, n_train, norm, mode, d_key1, d_key2, SLAM_MAX_ROWS);
+    if (rc != SLAM_OK || n_query == 0) return rc;
+    return match_single(who, d_query, n_query, d_train, n_train, norm, mode, d_key1, d_key2, (unsigned *)d_workspace,
+                        workspace_bytes, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same matcher for callers that cannot allocate (code under HIP graph capture, serving loops, harnesses that
+// forbid hipMalloc).  The per-split partial lists -- the scratch buffer slam_match_hamming takes from its caller's
+// workspace -- live in a file-scope device array instead: 2 lists x 64 splits x SLAM_MATCH_NOALLOC_MAX_ROWS keys
+// = 4 MiB, held by every GPU the library runs on until the process ends.  In host code the array's NAME is only a
+// stand-in for the symbol; its address on a device comes from hipGetSymbolAddress, asked once per device with that
+// device current, and only that pointer is handed to kernels.
+constexpr size_t NOALLOC_WORDS = 2 * (size_t)64 * SLAM_MATCH_NOALLOC_MAX_ROWS;
+static __device__ __align__(256) unsigned scratch[NOALLOC_WORDS];
+
+namespace {
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+unsigned *g_scratch_ptr[MAX_DEVICES];        // per device: that device's copy of `scratch`
+
+// the current device's copy of `scratch` (looked up on the first call on that device)
+int scratch_of_current_device(const char *who, hipStream_t st, unsigned **out) {
+    int dev = -1;
+    SLAM_HIP_CHECK(hipGetDevice(&dev));
+    SLAM_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "%s: device ordinal %d not supported (max %d)", who, dev, MAX_DEVICES);
+    if (st) {
+        int sdev = -1;
+        SLAM_HIP_CHECK(hipStreamGetDevice(st, &sdev));
+        SLAM_REQUIRE(sdev == dev, "%s: stream belongs to device %d but device %d is current", who, sdev, dev);
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        SLAM_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        SLAM_REQUIRE(p != nullptr, "%s: hipGetSymbolAddress returned a null address", who);
+        g_scratch_ptr[dev] = (unsigned *)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return SLAM_OK;
+}
+
+}  // namespace
+
+extern "C" int slam_match_hamming_noalloc(const uint8_t *d_query, int n_query, const uint8_t *d_train, int n_train,
+                                          int norm, int mode, uint32_t *d_key1, uint32_t *d_key2, void *stream) {
+    const char *who = "slam_match_hamming_noalloc";
+    // sizes beyond the static scratch are refused here, before anything is launched
+    const int rc = match_single_check_args(who, d_query, n_query, d_train, n_train, norm, mode, d_key1, d_key2,
+                                           SLAM_MATCH_NOALLOC_MAX_ROWS + 1);
+    if (rc != SLAM_OK || n_query == 0) return rc;
+    unsigned *part = nullptr;
+    const int rs = scratch_of_current_device(who, (hipStream_t)stream, &part);
+    if (rs != SLAM_OK) return rs;
+    return match_single(who, d_query, n_query, d_train, n_train, norm, mode, d_key1, d_key2, part,
+                        NOALLOC_WORDS * sizeof(unsigned), (hipStream_t)stream);
 }
 
 extern "C" int slam_match_hamming_batched(const uint8_t *d_desc, const int32_t *d_count, int n_max,
