@@ -11,17 +11,17 @@
 //   5. supporter mask of the winning hypothesis + LM refit.
 // Host <-> device synchronisation: one per RANSAC round (normally one) and one at the end.
 #include <algorithm>
-#include <atomic>
 #include <chrono>
-#include <condition_variable>
-#include <functional>
 #include <mutex>
 #include <cmath>
 #include <cstring>
-#include <thread>
 #include <vector>
 
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include "common.h"
+#include "host_pool.h"
 #include "kernels.h"
 #include "ransac_host.h"
 
@@ -145,96 +145,9 @@ __global__ void gather_best_kernel(const double *pose, const uint8_t *status, co
     if (k == 0) best_status[seg] = status[o];
 }
 
-// Host worker pool for the per-pair host steps (the loop replay).  Persistent: creating
-// and joining 16 threads per call costs several hundred microseconds, which sits on the critical path between a
-// chunk's RANSAC download and its mask / refit launch.  One job at a time (calls from different host threads queue on
-// `gate`); the calling thread works too.
-class HostPool {
-public:
-    static HostPool &get() {
-        static HostPool pool;
-        return pool;
-    }
-    void run(int n_chunks, const std::function<void(int)> &job) {
-        std::lock_guard<std::mutex> serial(gate);
-        {
-            std::lock_guard<std::mutex> lk(m);
-            fn = &job;
-            total = n_chunks;
-            next.store(0);
-            pending = n_chunks;
-            ++generation;
-        }
-        cv_work.notify_all();
-        work();
-        std::unique_lock<std::mutex> lk(m);
-        cv_done.wait(lk, [&] { return pending == 0; });
-        fn = nullptr;
-    }
-    int workers() const { return (int)threads.size() + 1; }
-
-private:
-    HostPool() {
-        unsigned hw = std::thread::hardware_concurrency();
-        int nt = (int)(hw ? hw : 4);
-        if (nt > 16) nt = 16;
-        for (int t = 1; t < nt; ++t) threads.emplace_back([this] { loop(); });
-    }
-    ~HostPool() {
-        {
-            std::lock_guard<std::mutex> lk(m);
-            stop = true;
-            ++generation;
-        }
-        cv_work.notify_all();
-        for (auto &t : threads) t.join();
-    }
-    void work() {
-        for (;;) {
-            const int c = next.fetch_add(1);
-            if (c >= total) return;
-            (*fn)(c);
-            std::lock_guard<std::mutex> lk(m);
-            if (--pending == 0) cv_done.notify_all();
-        }
-    }
-    void loop() {
-        unsigned long seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(m);
-                cv_work.wait(lk, [&] { return generation != seen; });
-                seen = generation;
-                if (stop) return;
-            }
-            work();
-        }
-    }
-    std::vector<std::thread> threads;
-    std::mutex gate, m;
-    std::condition_variable cv_work, cv_done;
-    const std::function<void(int)> *fn = nullptr;
-    std::atomic<int> next{0};
-    int total = 0, pending = 0;
-    unsigned long generation = 0;
-    bool stop = false;
-};
-
 template <typename F>
 void parallel_for(int n, int grain, F fn) {
-    HostPool &pool = HostPool::get();
-    int nt = pool.workers();
-    if (nt > (n + grain - 1) / grain) nt = (n + grain - 1) / grain;
-    if (nt <= 1) {
-        fn(0, n);
-        return;
-    }
-    const int per = (n + nt - 1) / nt;
-    const std::function<void(int)> job = [&](int c) {
-        const int a = c * per, e = a + per < n ? a + per : n;
-        if (a < e) fn(a, e);
-    };
-    pool.run(nt, job);
+    parallel_for(HostPool::get(), n, grain, fn);      // host_pool.h: persistent workers, capped per rank
 }
 
 thread_local double g_timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -574,40 +487,63 @@ double union_ms(std::vector<std::pair<float, float>> iv) {
     return total;
 }
 
-thread_local Lane g_lane[2];
-thread_local hipStream_t g_side_stream[2] = {nullptr, nullptr};
-thread_local hipEvent_t g_fork = nullptr;
-thread_local hipEvent_t g_base = nullptr;
-thread_local int g_device = -1;                      // device the streams / events above were created on
+// Per-host-thread HIP objects of slam_track_pairs: two lanes (events), two side streams, fork / base events.  They
+// belong to the device that was current when they were created.  A host thread that moves to another device between
+// calls gets a fresh set there (the old one is released: nothing of a finished call is still queued on it, every call
+// drains its lanes before it returns), and a worker thread that exits releases its set (a caller that runs
+// slam_track_pairs from short-lived threads would otherwise leak 16 events and 2 streams per thread).  The process'
+// main thread is left alone at exit: its thread-locals are destroyed while the HIP runtime is shutting down, and the
+// process is about to return everything anyway.
+struct ThreadState {
+    Lane lane[2];
+    hipStream_t side_stream[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr;
+    hipEvent_t base = nullptr;
+    int device = -1;                      // device the streams / events above were created on
 
-// Streams and events belong to the device that was current when they were created.  A host thread that moves to
-// another device between calls gets a fresh set there (the old one is released: nothing of a finished call is still
-// queued on it, every call drains its lanes before it returns).
-int bind_device() {
-    int dev = -1;
-    SLAM_HIP_CHECK(hipGetDevice(&dev));
-    if (dev == g_device) return SLAM_OK;
-    if (g_device >= 0) {
-        for (Lane &ln : g_lane)
+    void release() {
+        if (device < 0) return;
+        for (Lane &ln : lane)
             if (ln.ev_ready) {
                 for (auto &e : ln.ev) (void)hipEventDestroy(e);
                 for (auto &e : ln.evR) (void)hipEventDestroy(e);
                 ln.ev_ready = false;
             }
-        if (g_fork) {
-            (void)hipEventDestroy(g_fork);
-            g_fork = nullptr;
-            for (auto &s : g_side_stream) {
-                (void)hipStreamDestroy(s);
+        if (fork) {
+            (void)hipEventDestroy(fork);
+            fork = nullptr;
+            for (auto &s : side_stream) {
+                if (s) (void)hipStreamDestroy(s);
                 s = nullptr;
             }
         }
-        if (g_base) {
-            (void)hipEventDestroy(g_base);
-            g_base = nullptr;
+        if (base) {
+            (void)hipEventDestroy(base);
+            base = nullptr;
         }
+        device = -1;
     }
-    g_device = dev;
+    ~ThreadState() {
+        if ((long)syscall(SYS_gettid) == (long)getpid()) return;      // main thread at process exit
+        int cur = -1;
+        if (device < 0 || hipGetDevice(&cur) != hipSuccess) return;   // runtime already gone: nothing to release
+        if (cur != device && hipSetDevice(device) != hipSuccess) return;
+        release();                                                    // errors (hipErrorDeinitialized, ...) are ignored
+        if (cur != device) (void)hipSetDevice(cur);
+    }
+};
+thread_local ThreadState g_ts;
+
+int bind_device() {
+    int dev = -1;
+    SLAM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev == g_ts.device) return SLAM_OK;
+    if (g_ts.device >= 0) {
+        // objects of the previous device are destroyed with that device current
+        if (hipSetDevice(g_ts.device) == hipSuccess) g_ts.release();
+        SLAM_HIP_CHECK(hipSetDevice(dev));
+    }
+    g_ts.device = dev;
     return SLAM_OK;
 }
 
@@ -733,16 +669,16 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
         const size_t dl = lane_bytes(lane_F, lane_P, N, cfg, false), hl = lane_bytes(lane_F, lane_P, N, cfg, true);
         if (2 * dl > io->d_workspace_bytes || 2 * hl > io->h_workspace_bytes) chunks.clear();   // pairs not local in time
     }
-    Lane *L = g_lane;
+    Lane *L = g_ts.lane;
     {
         const int rc = bind_device();
         if (rc) return rc;
     }
-    if (!g_base) SLAM_HIP_CHECK(hipEventCreate(&g_base));
-    SLAM_HIP_CHECK(hipEventRecord(g_base, st));
+    if (!g_ts.base) SLAM_HIP_CHECK(hipEventCreate(&g_ts.base));
+    SLAM_HIP_CHECK(hipEventRecord(g_ts.base, st));
     for (int k = 0; k < 2; ++k) {
         L[k].host_ms = 0;
-        L[k].base = g_base;
+        L[k].base = g_ts.base;
         L[k].match_iv.clear();
         for (double &v : L[k].stage_ms) v = 0;
     }
@@ -766,17 +702,17 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
         }
         n_launch = 1;
     } else {
-        if (!g_fork) {
-            SLAM_HIP_CHECK(hipEventCreateWithFlags(&g_fork, hipEventDisableTiming));
-            for (auto &s : g_side_stream) SLAM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        if (!g_ts.fork) {
+            SLAM_HIP_CHECK(hipEventCreateWithFlags(&g_ts.fork, hipEventDisableTiming));
+            for (auto &s : g_ts.side_stream) SLAM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         }
         const size_t dl = lane_bytes(lane_F, lane_P, N, cfg, false), hl = lane_bytes(lane_F, lane_P, N, cfg, true);
-        SLAM_HIP_CHECK(hipEventRecord(g_fork, st));              // inputs were produced on the caller's stream
+        SLAM_HIP_CHECK(hipEventRecord(g_ts.fork, st));              // inputs were produced on the caller's stream
         for (int k = 0; k < 2; ++k) {
             Carver dc((char *)io->d_workspace + k * dl), hc((char *)io->h_workspace + k * hl);
             layout(lane_F, lane_P, N, cfg, dc, hc, L[k].b);
-            L[k].st = g_side_stream[k];
-            SLAM_HIP_CHECK(hipStreamWaitEvent(L[k].st, g_fork, 0));
+            L[k].st = g_ts.side_stream[k];
+            SLAM_HIP_CHECK(hipStreamWaitEvent(L[k].st, g_ts.fork, 0));
         }
         const int C = (int)chunks.size();
         int rc = SLAM_OK;
@@ -803,8 +739,8 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
         }
         if (rc) {
             // the first error is the one reported; still drain both lanes so no work outlives the call
-            (void)hipStreamSynchronize(g_side_stream[0]);
-            (void)hipStreamSynchronize(g_side_stream[1]);
+            (void)hipStreamSynchronize(g_ts.side_stream[0]);
+            (void)hipStreamSynchronize(g_ts.side_stream[1]);
             return rc;
         }
         n_launch = C;

@@ -46,10 +46,20 @@ class SynthConfig:
     mismatch_frac: float = 0.0    # share of landmark features whose right-image descriptor is swapped (stress)
     gross_frac: float = 0.04      # share of landmark detections per image with gross localisation error
     gross_sigma: float = 6.0      # pixels (1 sigma) of that gross error
+    gross_x_only: bool = False    # gross error along the image row only: it survives the stereo-row test (stress)
 
     @property
     def n_max(self) -> int:
         return (self.n_features + 63) // 64 * 64
+
+
+def stress_config(n_frames: int = 40, n_features: int = 8000, seed: int = 5) -> SynthConfig:
+    """BASELINE configs[3] / SURVEY 8(d) "Stress": 8k features per image, 60 % of the tracked correspondences outliers
+    of the pose (gross localisation errors along the image row, 15 px at 1 sigma, in 27 % of the detections: they pass
+    the stereo-row test, and a correspondence is an inlier only if all four of its detections are clean), T >= 3000
+    tracked correspondences per pair."""
+    return SynthConfig(n_frames=n_frames, n_features=n_features, true_frac=0.85, seed=seed, spawn_per_frame=800,
+                       mismatch_frac=0.05, gross_frac=0.27, gross_sigma=15.0, gross_x_only=True, ragged=31)
 
 
 def _rot_y(a):
@@ -151,7 +161,10 @@ class SynthSequence:
             p[:n_true, 1] = vv[cand] + rng.normal(0, cfg.px_noise, n_true)
             if cfg.gross_frac > 0 and n_true:
                 g = rng.random(n_true) < cfg.gross_frac
-                p[:n_true][g] += rng.normal(0, cfg.gross_sigma, (int(g.sum()), 2))
+                e = rng.normal(0, cfg.gross_sigma, (int(g.sum()), 2))
+                if cfg.gross_x_only:
+                    e[:, 1] = 0.0
+                p[:n_true][g] += e
             n_cl = n - n_true
             cl = rng.integers(0, 256, (n_cl, DESC_BYTES), dtype=np.uint8)
             cl[:, DESC_BYTES - 1] &= 0x3F

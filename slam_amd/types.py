@@ -204,6 +204,13 @@ class DataBase:
     ended a track in pair (i-1, i) extends that track; otherwise it opens a new one.  Track ids are assigned in
     encounter order, which is the order of the features inside each pair (ascending left key-point of frame i)."""
 
+    def __new__(cls, prev_and_next_frame_features=None, *args, **kwargs):
+        # Feature lists that are still index arrays (what find_features_in_consecutive_frames_whole_movie returns,
+        # LazyPairFeatures) go to the array-backed database: same accessors, no 4.5 M Feature objects in between.
+        if cls is DataBase and isinstance(prev_and_next_frame_features, LazyPairFeatures):
+            return object.__new__(ArrayDataBase)
+        return object.__new__(cls)
+
     def __init__(self, prev_and_next_frame_features, inliers_percentage, global_cam_trans, relative_cam_trans):
         self._tracks = []
         self._frames = []
@@ -339,6 +346,28 @@ class _LazyObjects:
         return self[:]
 
 
+class LazyPairFeatures(_LazyObjects):
+    """`consecutive_frame_features` of the whole-movie driver (utils/utills.py:867: one [frame-i features, frame-(i+1)
+    features] entry per pair) kept as the supporters' key-point index arrays; entry i becomes two object arrays of
+    Feature when it is read.  kp_pairs[i]: int[n_i, 4] (L_i, R_i, L_{i+1}, R_{i+1}); xy_frames[f]: float32[2, n, 2]."""
+
+    def __init__(self, kp_pairs, xy_frames):
+        self.kp_pairs, self.xy_frames = kp_pairs, xy_frames
+        super().__init__(len(kp_pairs), self._make)
+
+    def _make(self, i):
+        kp = self.kp_pairs[i]
+        out = []
+        for f, cols in ((i, (0, 1)), (i + 1, (2, 3))):
+            xl, xr = self.xy_frames[f][0], self.xy_frames[f][1]
+            a = np.empty(len(kp), dtype=object)
+            for j in range(len(kp)):
+                l, r = int(kp[j, cols[0]]), int(kp[j, cols[1]])
+                a[j] = Feature(l, r, float(xl[l, 0]), float(xr[r, 0]), float(xl[l, 1]), float(xr[r, 1]))
+            out.append(a)
+        return out
+
+
 class ArrayFrame(Frame):
     """Frame whose track ids stay an array until somebody appends to them."""
 
@@ -358,7 +387,18 @@ class ArrayDataBase(DataBase):
     Built straight from the hot path's index arrays (utills.whole_movie_database); equal, accessor by accessor, to
     DataBase built from the materialised Feature lists."""
 
-    def __init__(self, table, kp_pairs, xy_frames, inliers_percentage, global_cam_trans, relative_cam_trans):
+    def __init__(self, table, *args):
+        """ArrayDataBase(table, kp_pairs, xy_frames, inliers_percentage, global_cam_trans, relative_cam_trans), or the
+        reference's four constructor arguments with a LazyPairFeatures first (what DataBase(...) forwards here)."""
+        if isinstance(table, LazyPairFeatures):
+            from . import tracks
+            lazy = table
+            inliers_percentage, global_cam_trans, relative_cam_trans = args
+            kp_pairs, xy_frames = lazy.kp_pairs, lazy.xy_frames
+            table = tracks.chain_tracks(kp_pairs, xy_frames)
+        else:
+            lazy = None
+            kp_pairs, xy_frames, inliers_percentage, global_cam_trans, relative_cam_trans = args
         self._table = table
         self._kp_pairs, self._xy_frames = kp_pairs, xy_frames
         self._inliers_percentage = inliers_percentage
@@ -370,7 +410,7 @@ class ArrayDataBase(DataBase):
             frames[f] = ArrayFrame(f, global_cam_trans[f], ft[fp[f]:fp[f + 1]])
         self._frames = frames
         self._tracks = _LazyObjects(table.n_tracks, self._make_track)
-        self._pair_features = _LazyObjects(len(kp_pairs), self._make_pair_features)
+        self._pair_features = lazy if lazy is not None else LazyPairFeatures(kp_pairs, xy_frames)
 
     def _feature(self, row):
         t = self._table
@@ -384,18 +424,6 @@ class ArrayDataBase(DataBase):
         for row in range(t.track_ptr[tid], t.track_ptr[tid + 1]):
             tr.add_feature(int(t.obs_frame[row]), self._feature(row))
         return tr
-
-    def _make_pair_features(self, i):
-        kp = self._kp_pairs[i]
-        out = []
-        for f, cols in ((i, (0, 1)), (i + 1, (2, 3))):
-            xl, xr = self._xy_frames[f][0], self._xy_frames[f][1]
-            a = np.empty(len(kp), dtype=object)
-            for j in range(len(kp)):
-                l, r = int(kp[j, cols[0]]), int(kp[j, cols[1]])
-                a[j] = Feature(l, r, float(xl[l, 0]), float(xr[r, 0]), float(xl[l, 1]), float(xr[r, 1]))
-            out.append(a)
-        return out
 
     def get_table(self):
         return self._table

@@ -21,8 +21,8 @@ import torch
 from . import _lib, ops, pipeline, tracks, trajectory
 from .config import BRUTE_FORCE, FLANN_KNN, NORM_HAMMING, NORM_HAMMING2, REGULAR_KNN, HotPathConfig
 from .synth import K_KITTI, M1_KITTI, M2_KITTI
-from .types import (ArrayDataBase, DataBase, DMatch, Feature, Frame, KeyPoint, Track, dmatches_from_arrays, keypoints_from_xy,
-                    keypoints_to_xy)
+from .types import (ArrayDataBase, DataBase, DMatch, Feature, Frame, KeyPoint, LazyPairFeatures, Track, dmatches_from_arrays,
+                    keypoints_from_xy, keypoints_to_xy)
 
 # == module constants, as utills.py:17-42 ==
 K, M1, M2 = K_KITTI.copy(), M1_KITTI.copy(), M2_KITTI.copy()
@@ -572,36 +572,26 @@ def _check_pairs(res):
 
 def find_features_in_consecutive_frames_whole_movie(first_left_ex_cam_mat=M1, movie_len=None, seeds=None):
     """:834-873.  -> (consecutive_frame_features, inliers_percentage, global_trans, relative_trans): the four
-    constructor arguments of DataBase (DataBase.py:39)."""
-    n = movie_len if movie_len is not None else min(MOVIE_LEN, len(DETECTIONS)) if hasattr(DETECTIONS, "__len__") else MOVIE_LEN
-    frames = np.arange(n)
-    f0, f1 = pipeline.consecutive_pairs(n)
-    res, xy, kp = track_pairs_arrays(frames, f0, f1, seeds)
-    _check_pairs(res)
-    feats, percs, rel = [], [], [first_left_ex_cam_mat]
-    for p in range(n - 1):
-        T = int(res.stats[p, 0])
-        sup = kp[p, :T][res.mask[p, :T]]
-        feats.append([_features_of(sup[:, :2], xy[p]), _features_of(sup[:, 2:], xy[p + 1])])
-        percs.append(100 * int(res.stats[p, 1]) / T)
-        rel.append(res.pose[p] if res.ok[p] else None)
-    return feats, percs, convert_trans_from_rel_to_global(rel), rel
+    constructor arguments of DataBase (DataBase.py:39).
 
-
-def whole_movie_database(first_left_ex_cam_mat=M1, movie_len=None, seeds=None):
-    """find_features_in_consecutive_frames_whole_movie (:834-873) followed by DataBase(...) (Data.py:42-43) without
-    the Feature objects in between: the supporters' key-point indices go from the device arrays straight into the
-    array-backed track chaining (slam_amd/tracks.py).  Returns an ArrayDataBase, equal accessor by accessor to
-    DataBase(*find_features_in_consecutive_frames_whole_movie(...)) for the same seeds."""
+    consecutive_frame_features is a LazyPairFeatures: a sequence with one [frame-i Feature array, frame-(i+1) Feature
+    array] entry per pair, as the reference's list, whose entries are built from the supporters' index arrays when they
+    are read (a 3450-frame movie holds ~4.5 M Features; building them all up front took 8-12 s around a 17 ms device
+    pass).  DataBase(...) recognises it and chains the tracks on the index arrays (types.ArrayDataBase)."""
     n = movie_len if movie_len is not None else min(MOVIE_LEN, len(DETECTIONS)) if hasattr(DETECTIONS, "__len__") else MOVIE_LEN
     f0, f1 = pipeline.consecutive_pairs(n)
     res, xy, kp = track_pairs_arrays(np.arange(n), f0, f1, seeds)
     _check_pairs(res)
     sup = tracks.supporters_from_shard(res.stats, res.mask, kp)
-    percs = [100 * int(res.stats[p, 1]) / int(res.stats[p, 0]) for p in range(n - 1)]
+    T = res.stats[:, 0].astype(np.int64)
+    percs = (100 * res.stats[:, 1].astype(np.int64) / T).tolist()          # :923, true division of Python ints
     rel = [first_left_ex_cam_mat] + [res.pose[p] if res.ok[p] else None for p in range(n - 1)]
-    glob = convert_trans_from_rel_to_global(rel)
-    return ArrayDataBase(tracks.chain_tracks(sup, xy), sup, xy, percs, glob, rel)
+    return LazyPairFeatures(sup, xy), percs, convert_trans_from_rel_to_global(rel), rel
+
+
+def whole_movie_database(first_left_ex_cam_mat=M1, movie_len=None, seeds=None):
+    """DataBase(*find_features_in_consecutive_frames_whole_movie(...)) (Data.py:42-43) in one call; an ArrayDataBase."""
+    return DataBase(*find_features_in_consecutive_frames_whole_movie(first_left_ex_cam_mat, movie_len, seeds))
 
 
 def whole_movie(first_left_ex_mat=M1, movie_len=None, seeds=None):

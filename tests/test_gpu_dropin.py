@@ -109,8 +109,16 @@ def test_whole_movie_and_database(golden, movie):
     c_want = orc.camera_centres(orc.rel_to_global(want_rel))
     ate = np.sqrt(np.mean(np.sum((c_got - c_want) ** 2, axis=1)))
     assert ate <= 1e-3 * np.linalg.norm(c_want[-1])
-    db = types.DataBase(feats, percs, glob, rel)
-    assert db.get_num_frames() == F and db.get_num_tracks() > 100
+    # the feature lists arrive as index arrays (LazyPairFeatures): entry by entry they equal the eagerly built lists ...
+    assert isinstance(feats, types.LazyPairFeatures)
+    eager = [[U._features_of(s[:, :2], movie.xy[p]), U._features_of(s[:, 2:], movie.xy[p + 1])]
+             for p, s in enumerate(feats.kp_pairs)]
+    assert [[[f.__getstate__() for f in half] for half in pair] for pair in feats] == \
+           [[[f.__getstate__() for f in half] for half in pair] for pair in eager]
+    # ... DataBase(...) of the lazy lists (Data.py:43) is the array-backed database, of the eager lists the object one
+    assert isinstance(types.DataBase(feats, percs, glob, rel), types.ArrayDataBase)
+    db = types.DataBase(eager, percs, glob, rel)
+    assert type(db) is types.DataBase and db.get_num_frames() == F and db.get_num_tracks() > 100
     assert max(t.get_track_len() for t in db.get_tracks()) >= 3
     # row N1: the array-backed database built straight from the device index arrays is the same database
     adb = U.whole_movie_database(U.M1, seeds=seeds)
