@@ -37,9 +37,16 @@ extern "C" {
 #define SLAM_NORM_HAMMING 6
 #define SLAM_NORM_HAMMING2 7
 
-/* matcher modes: utils/utills.py:108-110 (cross-check brute force) and :112-119 (kNN, k = 2) */
+/* matcher modes: utils/utills.py:108-110 (cross-check brute force) and :112-119 (kNN, k = 2).
+ * cv2.BFMatcher(crossCheck=True) has had two behaviours and the reference pins no OpenCV version:
+ *   SLAM_MATCH_CROSSCHECK         batchDistance(crosscheck=true) as in OpenCV up to 4.5: every TRAIN row votes for its
+ *                                 nearest query; a query keeps the voter of least distance (lowest train row on ties).
+ *                                 It does not check that the train row is the query's own nearest.  The default.
+ *   SLAM_MATCH_CROSSCHECK_MUTUAL  newer OpenCV: both directions are computed and a pair is kept only if each row is
+ *                                 the other's nearest (first minimum on both sides).  Twice the distance work. */
 #define SLAM_MATCH_CROSSCHECK 0
 #define SLAM_MATCH_KNN2 1
+#define SLAM_MATCH_CROSSCHECK_MUTUAL 2
 
 #define SLAM_OK 0
 #define SLAM_E_INVALID (-1)     /* bad argument (null pointer, size out of range) */
@@ -54,8 +61,8 @@ const char *slam_last_error_string(void);
  * Matching.  Replaces cv2.BFMatcher(NORM_HAMMING2, crossCheck=True).match (utils/utills.py:57-70,
  * :105-110) and cv2.BFMatcher(...).knnMatch(.., 2) (utils/utills.py:92-102).
  *
- * SLAM_MATCH_CROSSCHECK: d_key1[i] = packed (distance, train row) matched to query row i under
- *   OpenCV's cross-check rule, or SLAM_KEY_NONE; d_key2 is not written (may be NULL).
+ * SLAM_MATCH_CROSSCHECK / _MUTUAL: d_key1[i] = packed (distance, train row) matched to query row i under
+ *   that cross-check rule, or SLAM_KEY_NONE; d_key2 is not written (may be NULL).
  * SLAM_MATCH_KNN2: d_key1[i] / d_key2[i] = nearest / second nearest train row of query i (ties:
  *   lower train index first).
  * d_query / d_train: [n][64] bytes, 16-byte aligned.  n_query, n_train < SLAM_MAX_ROWS.
@@ -80,11 +87,18 @@ int slam_match_hamming_noalloc(const uint8_t *d_query, int n_query, const uint8_
 
 /* Batched form: one launch for many image pairs.  Image k holds h/d_count[k] rows at
  * d_desc + k * n_max * 64.  Problem p matches query image prob_query[p] against train image
- * prob_train[p]; results go to d_key1 + p * n_max (and d_key2 + p * n_max for KNN2).
- * d_prob_query / d_prob_train / d_count are device int32 arrays.  No workspace. */
+ * prob_train[p]; results go to d_key1 + p * n_max (and d_key2 + p * n_max for KNN2): all n_max keys of every problem
+ * are written (SLAM_KEY_NONE beyond the query image's rows).
+ * d_prob_query / d_prob_train / d_count are device int32 arrays.
+ * ratio (KNN2 only): > 0 applies significance_test (utils/utills.py:131-152) on the device: d_key1[i] is kept only if
+ *   distance1 < ratio * distance2 in float64 (RATIO = 0.6, utils/utills.py:23); 0 = no test.
+ * Workspace: slam_match_batched_workspace_bytes(n_prob, n_max, mode) bytes of device memory (per-row nearest keys
+ * before the rule is applied; a batch too small to fill the chip also splits the scanned image over workgroups). */
+size_t slam_match_batched_workspace_bytes(int n_prob, int n_max, int mode);
 int slam_match_hamming_batched(const uint8_t *d_desc, const int32_t *d_count, int n_max, const int32_t *d_prob_query,
-                               const int32_t *d_prob_train, int n_prob, int norm, int mode, uint32_t *d_key1,
-                               uint32_t *d_key2, void *stream);
+                               const int32_t *d_prob_train, int n_prob, int norm, int mode, double ratio,
+                               uint32_t *d_key1, uint32_t *d_key2, void *d_workspace, size_t workspace_bytes,
+                               void *stream);
 
 /* Unpacks keys into the (trainIdx, distance) pairs of cv2.DMatch; -1 / INT32_MAX where there is no match. */
 int slam_unpack_keys(const uint32_t *d_key, int n, int32_t *d_index, int32_t *d_distance, void *stream);
@@ -215,6 +229,11 @@ typedef struct SlamTrackConfig {
     int32_t pipeline_taper_permille; /* size of each block relative to the previous one, in 1/1000: 0 or 1000 = equal
                                 blocks; e.g. 450 makes every block 0.45 x the one before, so the un-overlapped tail of
                                 the call belongs to a small block.  Results do not depend on it. */
+    int32_t match_mode;      /* how match() pairs descriptors (utils/utills.py:105-119): SLAM_MATCH_CROSSCHECK (default,
+                                MATCH_METHOD = BRUTE_FORCE), SLAM_MATCH_CROSSCHECK_MUTUAL, or SLAM_MATCH_KNN2
+                                (REGULAR_KNN: two nearest + the ratio test below) */
+    int32_t reserved_;
+    double ratio;            /* RATIO = 0.6 (utils/utills.py:23); used by SLAM_MATCH_KNN2 only; 0 = 0.6 */
 } SlamTrackConfig;
 
 typedef struct SlamTrackIO {

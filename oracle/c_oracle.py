@@ -22,6 +22,7 @@ def lib():
         _lib = ctypes.CDLL(_SO)
         _lib.oracle_match_crosscheck.restype = ctypes.c_int
         _lib.oracle_match_crosscheck_w64.restype = ctypes.c_int
+        _lib.oracle_match_crosscheck_mutual.restype = ctypes.c_int
     return _lib
 
 
@@ -29,15 +30,16 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def match_crosscheck(q, t, norm=7):
-    """(queryIdx, trainIdx, dist) ascending in queryIdx; byte-table code path."""
+def match_crosscheck(q, t, norm=7, mutual=False):
+    """(queryIdx, trainIdx, dist) ascending in queryIdx; byte-table code path.  mutual: the newer-OpenCV rule."""
     q = np.ascontiguousarray(q, dtype=np.uint8)
     t = np.ascontiguousarray(t, dtype=np.uint8)
     nq, nt = len(q), len(t)
     out_t = np.empty(nq, np.int32)
     out_d = np.empty(nq, np.int32)
-    lib().oracle_match_crosscheck(_p(q), nq, q.strides[0] if nq else 0, _p(t), nt, t.strides[0] if nt else 0,
-                                  q.shape[1] if nq else 0, norm, _p(out_t), _p(out_d))
+    fn = lib().oracle_match_crosscheck_mutual if mutual else lib().oracle_match_crosscheck
+    fn(_p(q), nq, q.strides[0] if nq else 0, _p(t), nt, t.strides[0] if nt else 0,
+       q.shape[1] if nq else 0, norm, _p(out_t), _p(out_d))
     qi = np.nonzero(out_t >= 0)[0].astype(np.int32)
     return qi, out_t[qi], out_d[qi]
 

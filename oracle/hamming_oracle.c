@@ -106,6 +106,34 @@ int oracle_match_crosscheck(const uint8_t *q, int nq, int stq, const uint8_t *t,
     return count;
 }
 
+/* The other behaviour BFMatcher(crossCheck=True) has had (newer OpenCV computes both directions in
+ * batchDistance and keeps train j for query tidx[j] only if sidx[tidx[j]] == j): mutual nearest rows,
+ * first minimum on both sides.  UNPINNED like the rule above.  Same outputs as oracle_match_crosscheck. */
+int oracle_match_crosscheck_mutual(const uint8_t *q, int nq, int stq, const uint8_t *t, int nt, int stt, int dbytes,
+                                   int norm, int32_t *out_train, int32_t *out_dist) {
+    init_tabs();
+    const uint8_t *tab = norm == ORACLE_NORM_HAMMING2 ? tab2 : tab1;
+    for (int i = 0; i < nq; ++i) { out_train[i] = -1; out_dist[i] = INT_MAX; }
+    if (nq == 0 || nt == 0) return 0;
+    int32_t *tidx = (int32_t *)malloc(sizeof(int32_t) * (size_t)nt);
+    int32_t *tdist = (int32_t *)malloc(sizeof(int32_t) * (size_t)nt);
+    int32_t *sidx = (int32_t *)malloc(sizeof(int32_t) * (size_t)nq);
+    int32_t *sdist = (int32_t *)malloc(sizeof(int32_t) * (size_t)nq);
+    batch_knn(t, nt, stt, q, nq, stq, dbytes, tab, 1, tidx, tdist);
+    batch_knn(q, nq, stq, t, nt, stt, dbytes, tab, 1, sidx, sdist);
+    int count = 0;
+    for (int j = 0; j < nt; ++j) {
+        int i = tidx[j];
+        if (tdist[j] < out_dist[i] && sidx[i] == j) {
+            if (out_train[i] < 0) ++count;
+            out_dist[i] = tdist[j];
+            out_train[i] = j;
+        }
+    }
+    free(tidx); free(tdist); free(sidx); free(sdist);
+    return count;
+}
+
 /* ---- word-parallel variant of the same matcher, used as the timed CPU baseline ("port") ----
  * Rows must be zero-padded to 64 bytes (16 dwords); identical results to the byte-table code above. */
 static inline int dist_words(const uint64_t *a, const uint64_t *b, int norm2) {

@@ -128,10 +128,32 @@ def crosscheck_from_matrix(D: np.ndarray):
     return q.astype(np.int32), best_j[q].astype(np.int32), best_d[q].astype(np.int32)
 
 
+def crosscheck_mutual_from_matrix(D: np.ndarray):
+    """The OTHER behaviour cv2.BFMatcher(crossCheck=True) has had (newer OpenCV
+    batch_distance.cpp computes both directions: tdist/tidx = nearest query of
+    every train row, sdist/sidx = nearest train of every query row, and keeps
+    train j for query i = tidx[j] only if sidx[i] == j): a pair survives iff each
+    row is the other's nearest, first minimum on both sides.  UNPINNED like the
+    legacy rule above -- the reference pins no OpenCV version, so both exist
+    here and in the HIP matcher (SLAM_MATCH_CROSSCHECK_MUTUAL)."""
+    nq, nt = D.shape
+    if nq == 0 or nt == 0:
+        z = np.zeros(0, np.int32)
+        return z, z, z
+    sidx = np.argmin(D, axis=1)                 # first minimum per query row
+    tidx = np.argmin(D, axis=0)                 # first minimum per train row
+    q = np.nonzero(tidx[sidx] == np.arange(nq))[0]
+    return q.astype(np.int32), sidx[q].astype(np.int32), D[q, sidx[q]].astype(np.int32)
+
+
 def bf_match(q_dsc, t_dsc, norm=NORM_HAMMING2):
     """Row 1: `match(..., BRUTE_FORCE)` = cross-check brute force, unsorted
     (utills.py:105-110).  Returns index arrays, not objects."""
     return crosscheck_from_matrix(hamming_matrix(q_dsc, t_dsc, norm))
+
+
+def bf_match_mutual(q_dsc, t_dsc, norm=NORM_HAMMING2):
+    return crosscheck_mutual_from_matrix(hamming_matrix(q_dsc, t_dsc, norm))
 
 
 def knn_ratio_match(q_dsc, t_dsc, norm=NORM_HAMMING2, ratio=RATIO):
@@ -627,22 +649,25 @@ def online_est_pnp_ransac(X, left1, M2_, right1, calib=K, acc=SUPP_ERR, model_pa
 # --------------------------------------------------------------------------
 # Row 11: per-pair driver and sequence composition
 # --------------------------------------------------------------------------
-def stereo_match(dsc_l, dsc_r, xy_l, xy_r, norm=NORM_HAMMING2):
+def stereo_match(dsc_l, dsc_r, xy_l, xy_r, norm=NORM_HAMMING2, matcher=None):
     """read_and_rec_match minus detection (utills.py:386-396)."""
-    q, t, d = bf_match(dsc_l, dsc_r, norm)
+    q, t, d = (matcher or bf_match)(dsc_l, dsc_r, norm)
     rec_idx, _ = rect_filter(xy_l[:, 1], xy_r[:, 1], q, t)
     return q, t, d, rec_idx
 
 
-def track_pair(frame0, frame1, calib=K, M1_=M1, M2_=M2, norm=NORM_HAMMING2, stats=None, **ransac_kw):
+def track_pair(frame0, frame1, calib=K, M1_=M1, M2_=M2, norm=NORM_HAMMING2, stats=None, matcher=None, **ransac_kw):
     """find_features_in_consecutive_frames (utills.py:876-925) on index arrays.
     frame = dict(dsc_l, dsc_r, xy_l, xy_r[, stereo]).  Returns dict with the
-    tracked key-point indices (L0, R0, L1, R1), points, pose, mask, inlier %."""
-    s0 = frame0.get("stereo") or stereo_match(frame0["dsc_l"], frame0["dsc_r"], frame0["xy_l"], frame0["xy_r"], norm)
-    s1 = frame1.get("stereo") or stereo_match(frame1["dsc_l"], frame1["dsc_r"], frame1["xy_l"], frame1["xy_r"], norm)
+    tracked key-point indices (L0, R0, L1, R1), points, pose, mask, inlier %.
+    matcher: what match() does (utills.py:105-119); default = bf_match (BRUTE_FORCE),
+    or bf_match_mutual / knn_ratio_match."""
+    matcher = matcher or bf_match
+    s0 = frame0.get("stereo") or stereo_match(frame0["dsc_l"], frame0["dsc_r"], frame0["xy_l"], frame0["xy_r"], norm, matcher)
+    s1 = frame1.get("stereo") or stereo_match(frame1["dsc_l"], frame1["dsc_r"], frame1["xy_l"], frame1["xy_r"], norm, matcher)
     q0, t0, _, rec0 = s0
     q1, t1, _, rec1 = s1
-    tq, tt, _ = bf_match(frame0["dsc_l"], frame1["dsc_l"], norm)
+    tq, tt, _ = matcher(frame0["dsc_l"], frame1["dsc_l"], norm)
     a, b, _ = join_4view(q0, rec0, q1, rec1, tq, tt)
     kp = np.stack([q0[a], t0[a], q1[b], t1[b]], axis=1).astype(np.int32) if len(a) else np.zeros((0, 4), np.int32)
     l0 = frame0["xy_l"][kp[:, 0]].astype(np.float64)

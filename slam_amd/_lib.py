@@ -15,6 +15,7 @@ SLAM_NORM_HAMMING = 6
 SLAM_NORM_HAMMING2 = 7
 SLAM_MATCH_CROSSCHECK = 0
 SLAM_MATCH_KNN2 = 1
+SLAM_MATCH_CROSSCHECK_MUTUAL = 2
 SLAM_KEY_SHIFT = 20
 SLAM_KEY_NONE = 0xFFFFFFFF
 SLAM_MATCH_NOALLOC_MAX_ROWS = 8192
@@ -30,7 +31,8 @@ class SlamTrackConfig(ctypes.Structure):
     _fields_ = [("K", c_double * 9), ("M1", c_double * 12), ("M2", c_double * 12), ("rec_err", c_double),
                 ("acc", c_double), ("prob", c_double), ("max_iterations", c_double),
                 ("fixed_iterations", ctypes.c_int32), ("max_draws", ctypes.c_int32), ("norm", ctypes.c_int32),
-                ("first_chunk", ctypes.c_int32), ("pipeline_chunks", ctypes.c_int32), ("pipeline_taper_permille", ctypes.c_int32)]
+                ("first_chunk", ctypes.c_int32), ("pipeline_chunks", ctypes.c_int32), ("pipeline_taper_permille", ctypes.c_int32),
+                ("match_mode", ctypes.c_int32), ("reserved_", ctypes.c_int32), ("ratio", c_double)]
 
 
 class SlamTrackIO(ctypes.Structure):
@@ -52,8 +54,9 @@ SIGNATURES = {
     "slam_match_hamming": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                    c_size_t, c_void_p]),
     "slam_match_hamming_noalloc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "slam_match_hamming_batched": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
-                                           c_void_p, c_void_p, c_void_p]),
+    "slam_match_batched_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "slam_match_hamming_batched": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_double,
+                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "slam_unpack_keys": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "slam_rect_filter_join": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                       c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

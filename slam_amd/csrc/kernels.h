@@ -6,7 +6,8 @@
 // takes (a permutation of 0 .. n_prob-1; NULL = identity).  Outputs are indexed by problem and do not depend on it.
 int slam_launch_match_batched(const uint8_t *d_desc, const int32_t *d_count, int n_max, const int32_t *d_prob_query,
                               const int32_t *d_prob_train, const int32_t *d_order, int n_prob, int norm, int mode,
-                              uint32_t *d_key1, uint32_t *d_key2, hipStream_t st);
+                              double ratio, uint32_t *d_key1, uint32_t *d_key2, void *d_workspace, size_t workspace_bytes,
+                              hipStream_t st);
 
 int slam_launch_rect_join(const float *d_xy, const int32_t *d_count, int n_max, const uint32_t *d_stereo_key,
                           const uint32_t *d_temporal_key, const int32_t *d_pair_f0, const int32_t *d_pair_f1,

@@ -21,9 +21,20 @@
 //   - the 32 distance chains of a B row (4 rows x 8 words) are issued side by side, one step of all of them at a
 //     time (32 x v_xor, 32 x v_bitop3, 32 x v_bcnt): the order matters by 15 % on this part.
 //   - tile shape (4 rows/lane, 256 threads, 128-row B tiles) chosen by a sweep on the MI355X.
-//   - cross-check (OpenCV batchDistance(crosscheck=true)): A = train rows; the nearest query of
-//     every train row is scattered with atomicMin on key (distance << 20 | train row) into the
-//     query's slot.  min is order independent, so the result is deterministic.
+//   - the all-pairs kernel only finds, for every A row, its nearest (kNN: two nearest) B row, and writes those keys
+//     with plain stores; a small second kernel (resolve_kernel, one workgroup per problem) merges the B splits and
+//     applies the matching rule on them:
+//       SLAM_MATCH_CROSSCHECK (OpenCV batchDistance(crosscheck=true), the one-directional rule of OpenCV <= 4.5):
+//         A = train rows; (distance, train row) of every train row is min-ed into its nearest query's slot in LDS
+//         (min is order independent, so the result is deterministic), then the slots are stored as whole rows;
+//       SLAM_MATCH_CROSSCHECK_MUTUAL (newer OpenCV: both directions computed, a pair is kept only if each row is the
+//         other's first-minimum nearest): both directions go through the all-pairs kernel, resolve compares them;
+//       SLAM_MATCH_KNN2 (+ optional ratio test d1 < ratio * d2 in float64): merge of the per-split top-2 lists.
+//     (Round 1 scattered straight from the all-pairs kernel with global atomicMin: 6.8 M device-scope atomics per
+//     shard, each a 64-byte memory transaction, 0.39 GB of writes for 57 MB of keys.)
+//   - a batch of few problems (a loop-closure call with 3-5 candidates) splits B over blockIdx.y until the grid fills
+//     the chip; the resolve kernel merges the splits.
+#include <algorithm>
 #include <mutex>
 #include <type_traits>
 
@@ -68,8 +79,9 @@ struct MatchBatch {
     const uint4 *b_ptr;
     int na, nb;               // single problem sizes
     int n_max;                // rows per image slot
-    unsigned *out1, *out2;    // per problem stride out_stride (top-1 / top-2 keys, or cross-check slots)
-    int out_stride;
+    unsigned *out1, *out2;    // nearest / second nearest B row of every A row: [problem][split][part_rows] keys
+    int out_stride;           // keys per problem = nsplit * part_rows
+    int part_rows;            // keys per split (>= A rows of any problem)
     int tiles_per_prob;       // A tiles per problem
     int nsplit;               // B splits (blockIdx.y)
     int n_prob;
@@ -128,11 +140,10 @@ __device__ __forceinline__ void top2_insert(unsigned &m1, unsigned &m2, unsigned
     m1 = min(m1, key);
 }
 
-// FUSED: cross-check scatter straight from the all-pairs kernel (nsplit == 1).
-// TOP2: keep the second best too (kNN mode); cross-check needs only the nearest row.
+// TOP2: keep the second best too (kNN mode); the cross-check rules need only the nearest row.
 // RW = A rows per lane: ROWS (4) where the grid fills the chip, 2 for a batch of few problems (twice as many
 // wavefronts for the same work, see launch_allpairs).
-template <bool NORM2, bool FUSED, bool TOP2, int RW>
+template <bool NORM2, bool TOP2, int RW>
 __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
     __shared__ uint4 tile[2][TILE_B * 4];
     constexpr int ROWS = RW;                 // shadows the file-scope default inside the kernel
@@ -333,39 +344,107 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
     for (int r = 0; r < ROWS; ++r) {
         const int row = slot_row(r);
         if (row >= na) continue;
-        if (FUSED) {
-            // A = train rows, B = query rows: scatter (distance, train row) into the nearest query's slot
-            if (m1[r] != NONE) {
-                const unsigned q = m1[r] & (SLAM_MAX_ROWS - 1);
-                const unsigned key = (m1[r] & ~(unsigned)(SLAM_MAX_ROWS - 1)) | (unsigned)row;
-                atomicMin(mb.out1 + (size_t)p * mb.out_stride + q, key);
-            }
-        } else {
-            const size_t o = (size_t)p * mb.out_stride + (size_t)split * na + row;
-            mb.out1[o] = m1[r];
-            if (mb.out2) mb.out2[o] = m2[r];
-        }
+        const size_t o = (size_t)p * mb.out_stride + (size_t)split * mb.part_rows + row;
+        mb.out1[o] = m1[r];
+        if (TOP2) mb.out2[o] = m2[r];
     }
 }
 
-// merges per-split partial top-2 lists of one problem; mode cross-check scatters, mode knn2 writes keys
-__global__ void merge_splits_kernel(const unsigned *part1, const unsigned *part2, int na, int nsplit, int crosscheck,
-                                    unsigned *out1, unsigned *out2) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= na) return;
-    unsigned m1 = NONE, m2 = NONE;
-    for (int s = 0; s < nsplit; ++s) {
-        top2_insert(m1, m2, part1[(size_t)s * na + row]);
-        if (part2) top2_insert(m1, m2, part2[(size_t)s * na + row]);
+// ---------------------------------------------------------------------------------------------------------------
+// Second kernel: one workgroup per problem merges the B splits of the per-row keys and applies the matching rule.
+struct ResolveArgs {
+    const unsigned *part1, *part2;   // all-pairs output: [problem (x2 directions for MUTUAL)][split][part_rows]
+    int nsplit, part_rows, part_stride;
+    const int *count, *prob_q, *prob_t;   // batched: rows per image, query / train image per problem
+    int nq, nt;                      // single problem
+    int n_prob;
+    unsigned *out1, *out2;           // final keys, out_stride per problem
+    int out_stride, out_rows;        // out_rows keys of every problem are written (rows beyond nq: SLAM_KEY_NONE)
+    double ratio;                    // KNN2: > 0 applies the ratio test to key1
+    int slots_in_lds;                // CROSSCHECK: query slots fit the LDS array (else global atomics on a pre-set out1)
+};
+
+constexpr int RESOLVE_BLOCK = 256;
+constexpr int LDS_SLOTS = 8192;      // 32 KB: query rows of one problem whose cross-check slots are reduced in LDS
+
+__device__ __forceinline__ unsigned merged_top1(const unsigned *part, int nsplit, int part_rows, int row) {
+    unsigned m = NONE;
+    for (int s = 0; s < nsplit; ++s) m = min(m, part[(size_t)s * part_rows + row]);
+    return m;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(RESOLVE_BLOCK) void resolve_kernel(ResolveArgs ra) {
+    __shared__ unsigned slot[MODE == SLAM_MATCH_CROSSCHECK ? LDS_SLOTS : 1];
+    const int p = blockIdx.x;
+    int nq, nt;
+    if (ra.count) {
+        nq = ra.count[ra.prob_q[p]];
+        nt = ra.count[ra.prob_t[p]];
+    } else {
+        nq = ra.nq;
+        nt = ra.nt;
     }
-    if (crosscheck) {
-        if (m1 != NONE) {
-            const unsigned q = m1 & (SLAM_MAX_ROWS - 1);
-            atomicMin(out1 + q, (m1 & ~(unsigned)(SLAM_MAX_ROWS - 1)) | (unsigned)row);
+    unsigned *out1 = ra.out1 + (size_t)p * ra.out_stride;
+    const unsigned idx_mask = SLAM_MAX_ROWS - 1;
+    if (MODE == SLAM_MATCH_CROSSCHECK) {
+        // lanes of the all-pairs kernel owned TRAIN rows: part1[j] = (distance, nearest query) of train row j.
+        // OpenCV's legacy rule: per query the train row of least distance among those whose nearest query it is
+        // (ties: lowest train row) = min over (distance << 20 | train row) per query slot.
+        const unsigned *part = ra.part1 + (size_t)p * ra.part_stride;
+        if (ra.slots_in_lds) {
+            for (int i = threadIdx.x; i < nq; i += RESOLVE_BLOCK) slot[i] = NONE;
+            __syncthreads();
+            for (int j = threadIdx.x; j < nt; j += RESOLVE_BLOCK) {
+                const unsigned m = merged_top1(part, ra.nsplit, ra.part_rows, j);
+                if (m != NONE) atomicMin(&slot[m & idx_mask], (m & ~idx_mask) | (unsigned)j);
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < ra.out_rows; i += RESOLVE_BLOCK) out1[i] = i < nq ? slot[i] : NONE;
+        } else {
+            // more query rows than LDS slots: out1 was set to SLAM_KEY_NONE by the host; scatter with global atomics
+            for (int j = threadIdx.x; j < nt; j += RESOLVE_BLOCK) {
+                const unsigned m = merged_top1(part, ra.nsplit, ra.part_rows, j);
+                if (m != NONE) atomicMin(out1 + (m & idx_mask), (m & ~idx_mask) | (unsigned)j);
+            }
+        }
+    } else if (MODE == SLAM_MATCH_CROSSCHECK_MUTUAL) {
+        // direction T (problem p): lanes owned train rows, part = nearest query of every train row;
+        // direction Q (problem n_prob + p): lanes owned query rows, part = nearest train of every query row.
+        // Query i keeps its nearest train j (first minimum) iff j's nearest query (first minimum) is i.
+        const unsigned *part_t = ra.part1 + (size_t)p * ra.part_stride;
+        const unsigned *part_q = ra.part1 + (size_t)(ra.n_prob + p) * ra.part_stride;
+        for (int i = threadIdx.x; i < ra.out_rows; i += RESOLVE_BLOCK) {
+            unsigned key = NONE;
+            if (i < nq) {
+                const unsigned mq = merged_top1(part_q, ra.nsplit, ra.part_rows, i);
+                if (mq != NONE) {
+                    const unsigned mt = merged_top1(part_t, ra.nsplit, ra.part_rows, (int)(mq & idx_mask));
+                    if (mt != NONE && (mt & idx_mask) == (unsigned)i) key = mq;
+                }
+            }
+            out1[i] = key;
         }
     } else {
-        out1[row] = m1;
-        if (out2) out2[row] = m2;
+        // kNN (k = 2): lanes owned query rows; merge the per-split lists (lower train row first on equal distance)
+        const unsigned *p1 = ra.part1 + (size_t)p * ra.part_stride, *p2 = ra.part2 + (size_t)p * ra.part_stride;
+        unsigned *out2 = ra.out2 + (size_t)p * ra.out_stride;
+        for (int i = threadIdx.x; i < ra.out_rows; i += RESOLVE_BLOCK) {
+            unsigned m1 = NONE, m2 = NONE;
+            if (i < nq)
+                for (int s = 0; s < ra.nsplit; ++s) {
+                    top2_insert(m1, m2, p1[(size_t)s * ra.part_rows + i]);
+                    top2_insert(m1, m2, p2[(size_t)s * ra.part_rows + i]);
+                }
+            if (ra.ratio > 0.0 && m1 != NONE) {
+                // significance_test (utils/utills.py:131-152): first.distance < ratio * second.distance in float64;
+                // a query with a single neighbour has no `second` (the reference cannot unpack it): dropped
+                const double d1 = (double)(m1 >> SLAM_KEY_SHIFT), d2 = (double)(m2 >> SLAM_KEY_SHIFT);
+                if (m2 == NONE || !(d1 < ra.ratio * d2)) m1 = NONE;
+            }
+            out1[i] = m1;
+            out2[i] = m2;
+        }
     }
 }
 
@@ -380,8 +459,9 @@ __global__ void unpack_keys_kernel(const unsigned *key, int n, int *index, int *
 // Workgroups the chip holds at once: 256 CUs x 3 (139 VGPRs = 3 wavefronts per SIMD, 4 wavefronts per workgroup).
 constexpr unsigned CHIP_WORKGROUPS = 768;
 constexpr int ROWS_SMALL = 2;
+constexpr int MAX_SPLIT = 64;
 
-template <bool FUSED, int RW>
+template <int RW>
 void launch_allpairs_rows(MatchBatch mb, int a_rows, int norm, hipStream_t st) {
     mb.tiles_per_prob = slam_div_up(a_rows, RW * BLOCK);
     const unsigned total = (unsigned)mb.tiles_per_prob * (unsigned)mb.n_prob;
@@ -389,91 +469,158 @@ void launch_allpairs_rows(MatchBatch mb, int a_rows, int norm, hipStream_t st) {
     const bool top2 = mb.out2 != nullptr;
     if (norm == SLAM_NORM_HAMMING2) {
         if (top2)
-            hipLaunchKernelGGL((allpairs_top2_kernel<true, false, true, RW>), grid, dim3(BLOCK), 0, st, mb);
+            hipLaunchKernelGGL((allpairs_top2_kernel<true, true, RW>), grid, dim3(BLOCK), 0, st, mb);
         else
-            hipLaunchKernelGGL((allpairs_top2_kernel<true, FUSED, false, RW>), grid, dim3(BLOCK), 0, st, mb);
+            hipLaunchKernelGGL((allpairs_top2_kernel<true, false, RW>), grid, dim3(BLOCK), 0, st, mb);
     } else {
         if (top2)
-            hipLaunchKernelGGL((allpairs_top2_kernel<false, false, true, RW>), grid, dim3(BLOCK), 0, st, mb);
+            hipLaunchKernelGGL((allpairs_top2_kernel<false, true, RW>), grid, dim3(BLOCK), 0, st, mb);
         else
-            hipLaunchKernelGGL((allpairs_top2_kernel<false, FUSED, false, RW>), grid, dim3(BLOCK), 0, st, mb);
+            hipLaunchKernelGGL((allpairs_top2_kernel<false, false, RW>), grid, dim3(BLOCK), 0, st, mb);
     }
 }
 
-// a_rows = A rows per problem slot (the tile grid covers them).  A batch of few problems (the stress configuration:
-// 59 problems of 8k x 8k rows = 472 workgroups at 4 rows per lane) leaves a third of the chip's wavefront slots empty;
-// it runs with 2 rows per lane instead: twice the wavefronts for the same distances.  At full load 4 rows per lane is
-// 9 % faster (DESIGN.md tile sweep), so that stays the choice whenever the grid fills the chip.
-template <bool FUSED>
+// rows per lane for a grid of n_prob problems with a_rows A rows each: 4 where that fills the chip (9 % faster at
+// full load, DESIGN.md tile sweep), else 2 (twice the wavefronts for the same distances)
+bool small_grid(int n_prob, int a_rows) {
+    return ROWS > ROWS_SMALL && (unsigned)slam_div_up(a_rows, TILE_A) * (unsigned)n_prob < CHIP_WORKGROUPS;
+}
+
 void launch_allpairs(const MatchBatch &mb, int a_rows, int norm, hipStream_t st) {
-    const unsigned total4 = (unsigned)slam_div_up(a_rows, TILE_A) * (unsigned)mb.n_prob * (unsigned)mb.nsplit;
-    if (ROWS > ROWS_SMALL && total4 < CHIP_WORKGROUPS)
-        launch_allpairs_rows<FUSED, ROWS_SMALL>(mb, a_rows, norm, st);
+    if (small_grid(mb.n_prob, a_rows))
+        launch_allpairs_rows<ROWS_SMALL>(mb, a_rows, norm, st);
     else
-        launch_allpairs_rows<FUSED, ROWS>(mb, a_rows, norm, st);
+        launch_allpairs_rows<ROWS>(mb, a_rows, norm, st);
 }
 
-int pick_nsplit(int na, int nb) {
-    const int tiles_a = slam_div_up(na, TILE_A), tiles_b = slam_div_up(nb, TILE_B);
-    int ns = 1024 / (tiles_a > 0 ? tiles_a : 1);
+// B splits for n_prob problems of a_rows x b_rows: 1 when the A tiles alone fill the chip, else enough splits for about
+// 1024 workgroups (each split scans at least one B tile)
+int pick_nsplit(int n_prob, int a_rows, int b_rows) {
+    const long tiles_a = (long)slam_div_up(a_rows, small_grid(n_prob, a_rows) ? ROWS_SMALL * BLOCK : TILE_A) * (n_prob > 0 ? n_prob : 1);
+    const int tiles_b = slam_div_up(b_rows, TILE_B);
+    if (tiles_a >= CHIP_WORKGROUPS) return 1;
+    long ns = 1024 / (tiles_a > 0 ? tiles_a : 1);
     if (ns > tiles_b) ns = tiles_b;
-    if (ns > 64) ns = 64;
-    return ns < 1 ? 1 : ns;
+    if (ns > MAX_SPLIT) ns = MAX_SPLIT;
+    return ns < 1 ? 1 : (int)ns;
 }
 
-}  // namespace
-
-extern "C" size_t slam_match_workspace_bytes(int n_query, int n_train) {
-    const size_t n = (size_t)(n_query > n_train ? n_query : n_train);
-    return 2 * 64 * n * sizeof(unsigned) + 256;
+// keys of scratch a match call needs: per direction and list, n_prob x nsplit x part_rows
+size_t scratch_keys(int n_prob, int part_rows, int nsplit, int mode) {
+    const size_t lists = mode == SLAM_MATCH_CROSSCHECK ? 1 : 2;       // MUTUAL: two directions; KNN2: two lists
+    return lists * (size_t)n_prob * (size_t)nsplit * (size_t)part_rows;
 }
 
-namespace {
+template <int MODE>
+void launch_resolve(const ResolveArgs &ra, hipStream_t st) {
+    hipLaunchKernelGGL((resolve_kernel<MODE>), dim3(ra.n_prob), dim3(RESOLVE_BLOCK), 0, st, ra);
+}
 
-// One problem: B split over blockIdx.y into per-split partial lists (`part`, 2 * nsplit * na keys), then merged.
-// Every key of the partial lists the merge reads is written by the all-pairs kernel first (rows < na of every split,
-// empty splits write SLAM_KEY_NONE), so `part` needs no clearing.
-int match_single(const char *who, const uint8_t *d_query, int n_query, const uint8_t *d_train, int n_train, int norm,
-                 int mode, uint32_t *d_key1, uint32_t *d_key2, unsigned *part, size_t part_bytes, hipStream_t st) {
-    const bool cross = mode == SLAM_MATCH_CROSSCHECK;
-    SLAM_HIP_CHECK(hipMemsetAsync(d_key1, 0xFF, sizeof(uint32_t) * (size_t)n_query, st));
-    if (!cross) SLAM_HIP_CHECK(hipMemsetAsync(d_key2, 0xFF, sizeof(uint32_t) * (size_t)n_query, st));
-    if (n_train == 0) return SLAM_OK;
-
-    MatchBatch mb{};
-    // cross-check: lanes own TRAIN rows and scan the queries; knn: lanes own QUERY rows and scan the trains
-    mb.a_ptr = (const uint4 *)(cross ? d_train : d_query);
-    mb.b_ptr = (const uint4 *)(cross ? d_query : d_train);
-    mb.na = cross ? n_train : n_query;
-    mb.nb = cross ? n_query : n_train;
-    mb.n_prob = 1;
-    mb.nsplit = pick_nsplit(mb.na, mb.nb);
-    const size_t need = 2 * (size_t)mb.nsplit * mb.na * sizeof(unsigned);
-    if (part_bytes < need || !part) {
-        slam_set_error("%s: workspace %zu B < %zu B", who, part_bytes, need);
+// The whole match: all-pairs (both directions for MUTUAL) into `scratch`, then resolve into out1 / out2.
+// `mb` arrives with the QUERY side in (prob_a | a_ptr, na) and the TRAIN side in (prob_b | b_ptr, nb).
+int run_match(const char *who, MatchBatch mb, int q_rows, int t_rows, int norm, int mode, double ratio, uint32_t *d_key1,
+              uint32_t *d_key2, int out_stride, int out_rows, unsigned *scratch, size_t scratch_bytes, hipStream_t st) {
+    const bool knn = mode == SLAM_MATCH_KNN2, mutual = mode == SLAM_MATCH_CROSSCHECK_MUTUAL;
+    const int n_prob = mb.n_prob;
+    // one split count for both directions, so that they share the partial layout
+    const int part_rows = q_rows > t_rows ? q_rows : t_rows;
+    int nsplit = knn ? pick_nsplit(n_prob, q_rows, t_rows) : pick_nsplit(n_prob, t_rows, q_rows);
+    if (mutual) nsplit = std::min(nsplit, pick_nsplit(n_prob, q_rows, t_rows));
+    const size_t need = scratch_keys(n_prob, part_rows, nsplit, mode) * sizeof(unsigned);
+    if (scratch_bytes < need || !scratch) {
+        slam_set_error("%s: workspace %zu B < %zu B", who, scratch_bytes, need);
         return SLAM_E_WORKSPACE;
     }
-    unsigned *part1 = part;
-    unsigned *part2 = part1 + (size_t)mb.nsplit * mb.na;
-    mb.out1 = part1;
-    mb.out2 = cross ? nullptr : part2;
-    mb.out_stride = 0;
-    launch_allpairs_rows<false, ROWS>(mb, mb.na, norm, st);      // B is split until the grid fills the chip (pick_nsplit)
+    const size_t dir_keys = (size_t)n_prob * nsplit * part_rows;
+    MatchBatch fwd = mb;                       // lanes own QUERY rows, scan the train rows
+    MatchBatch rev = mb;                       // lanes own TRAIN rows, scan the query rows
+    std::swap(rev.prob_a, rev.prob_b);
+    std::swap(rev.a_ptr, rev.b_ptr);
+    std::swap(rev.na, rev.nb);
+    for (MatchBatch *m : {&fwd, &rev}) {
+        m->nsplit = nsplit;
+        m->part_rows = part_rows;
+        m->out_stride = nsplit * part_rows;
+        m->out2 = nullptr;
+    }
+    if (knn) {
+        fwd.out1 = scratch;
+        fwd.out2 = scratch + dir_keys;
+        launch_allpairs(fwd, q_rows, norm, st);
+    } else {
+        rev.out1 = scratch;
+        launch_allpairs(rev, t_rows, norm, st);
+        if (mutual) {
+            fwd.out1 = scratch + dir_keys;
+            launch_allpairs(fwd, q_rows, norm, st);
+        }
+    }
     SLAM_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(merge_splits_kernel, dim3(slam_div_up(mb.na, 256)), dim3(256), 0, st, part1, mb.out2, mb.na,
-                       mb.nsplit, cross ? 1 : 0, d_key1, d_key2);
+
+    ResolveArgs ra{};
+    ra.part1 = scratch;
+    ra.part2 = knn ? scratch + dir_keys : nullptr;
+    ra.nsplit = nsplit;
+    ra.part_rows = part_rows;
+    ra.part_stride = nsplit * part_rows;
+    ra.count = mb.count;
+    ra.prob_q = mb.prob_a;
+    ra.prob_t = mb.prob_b;
+    ra.nq = mb.na;
+    ra.nt = mb.nb;
+    ra.n_prob = n_prob;
+    ra.out1 = d_key1;
+    ra.out2 = d_key2;
+    ra.out_stride = out_stride;
+    ra.out_rows = out_rows;
+    ra.ratio = ratio;
+    ra.slots_in_lds = q_rows <= LDS_SLOTS;
+    if (mode == SLAM_MATCH_CROSSCHECK) {
+        if (!ra.slots_in_lds)
+            SLAM_HIP_CHECK(hipMemsetAsync(d_key1, 0xFF, sizeof(uint32_t) * ((size_t)(n_prob - 1) * out_stride + out_rows), st));
+        launch_resolve<SLAM_MATCH_CROSSCHECK>(ra, st);
+    } else if (mutual) {
+        launch_resolve<SLAM_MATCH_CROSSCHECK_MUTUAL>(ra, st);
+    } else {
+        launch_resolve<SLAM_MATCH_KNN2>(ra, st);
+    }
     SLAM_HIP_CHECK(hipGetLastError());
     return SLAM_OK;
 }
 
+int check_mode(const char *who, int norm, int mode) {
+    SLAM_REQUIRE(norm == SLAM_NORM_HAMMING || norm == SLAM_NORM_HAMMING2, "%s: norm %d unsupported", who, norm);
+    SLAM_REQUIRE(mode == SLAM_MATCH_CROSSCHECK || mode == SLAM_MATCH_KNN2 || mode == SLAM_MATCH_CROSSCHECK_MUTUAL,
+                 "%s: mode %d unsupported", who, mode);
+    return SLAM_OK;
+}
+
+// One problem.  Every key the resolve kernel reads is written by the all-pairs kernel first (rows < na of every split;
+// empty splits write SLAM_KEY_NONE), so `scratch` needs no clearing between calls.
+int match_single(const char *who, const uint8_t *d_query, int n_query, const uint8_t *d_train, int n_train, int norm,
+                 int mode, uint32_t *d_key1, uint32_t *d_key2, unsigned *scratch, size_t scratch_bytes, hipStream_t st) {
+    if (n_train == 0) {
+        SLAM_HIP_CHECK(hipMemsetAsync(d_key1, 0xFF, sizeof(uint32_t) * (size_t)n_query, st));
+        if (mode == SLAM_MATCH_KNN2) SLAM_HIP_CHECK(hipMemsetAsync(d_key2, 0xFF, sizeof(uint32_t) * (size_t)n_query, st));
+        return SLAM_OK;
+    }
+    MatchBatch mb{};
+    mb.a_ptr = (const uint4 *)d_query;
+    mb.b_ptr = (const uint4 *)d_train;
+    mb.na = n_query;
+    mb.nb = n_train;
+    mb.n_prob = 1;
+    return run_match(who, mb, n_query, n_train, norm, mode, 0.0, d_key1, d_key2, 0, n_query, scratch, scratch_bytes, st);
+}
+
 int match_single_check_args(const char *who, const uint8_t *d_query, int n_query, const uint8_t *d_train, int n_train,
                             int norm, int mode, const uint32_t *d_key1, const uint32_t *d_key2, int max_rows) {
-    SLAM_REQUIRE(norm == SLAM_NORM_HAMMING || norm == SLAM_NORM_HAMMING2, "%s: norm %d unsupported", who, norm);
-    SLAM_REQUIRE(mode == SLAM_MATCH_CROSSCHECK || mode == SLAM_MATCH_KNN2, "%s: mode %d unsupported", who, mode);
+    const int rc = check_mode(who, norm, mode);
+    if (rc) return rc;
     SLAM_REQUIRE(n_query >= 0 && n_train >= 0 && n_query < max_rows && n_train < max_rows,
                  "%s: row counts %d/%d out of range (each must be below %d)", who, n_query, n_train, max_rows);
     if (n_query == 0) return SLAM_OK;
-    SLAM_REQUIRE(d_key1 && (mode == SLAM_MATCH_CROSSCHECK || d_key2), "%s: null output", who);
+    SLAM_REQUIRE(d_key1 && (mode != SLAM_MATCH_KNN2 || d_key2), "%s: null output", who);
     SLAM_REQUIRE(d_query && (d_train || n_train == 0), "%s: null input", who);
     SLAM_REQUIRE(((uintptr_t)d_query & 15) == 0 && ((uintptr_t)d_train & 15) == 0,
                  "%s: descriptor rows must be 16-byte aligned", who);
@@ -481,6 +628,11 @@ int match_single_check_args(const char *who, const uint8_t *d_query, int n_query
 }
 
 }  // namespace
+
+extern "C" size_t slam_match_workspace_bytes(int n_query, int n_train) {
+    const size_t n = (size_t)(n_query > n_train ? n_query : n_train);
+    return 2 * MAX_SPLIT * n * sizeof(unsigned) + 256;        // two lists / directions x at most 64 splits
+}
 
 extern "C" int slam_match_hamming(const uint8_t *d_query, int n_query, const uint8_t *d_train, int n_train, int norm,
                                   int mode, uint32_t *d_key1, uint32_t *d_key2, void *d_workspace,
@@ -499,7 +651,7 @@ extern "C" int slam_match_hamming(const uint8_t *d_query, int n_query, const uin
 // = 4 MiB, held by every GPU the library runs on until the process ends.  In host code the array's NAME is only a
 // stand-in for the symbol; its address on a device comes from hipGetSymbolAddress, asked once per device with that
 // device current, and only that pointer is handed to kernels.
-constexpr size_t NOALLOC_WORDS = 2 * (size_t)64 * SLAM_MATCH_NOALLOC_MAX_ROWS;
+constexpr size_t NOALLOC_WORDS = 2 * (size_t)MAX_SPLIT * SLAM_MATCH_NOALLOC_MAX_ROWS;
 static __device__ __align__(256) unsigned scratch[NOALLOC_WORDS];
 
 namespace {
@@ -545,44 +697,46 @@ extern "C" int slam_match_hamming_noalloc(const uint8_t *d_query, int n_query, c
                         NOALLOC_WORDS * sizeof(unsigned), (hipStream_t)stream);
 }
 
+// Enough for ANY batch of up to n_prob problems (a caller sizes one workspace for its largest batch and reuses it for
+// smaller ones, which split B more often): n x nsplit(n) <= max(n, min(n x B tiles, 1024 / A tiles per problem)).
+extern "C" size_t slam_match_batched_workspace_bytes(int n_prob, int n_max, int mode) {
+    if (n_prob <= 0 || n_max <= 0) return 256;
+    const long tiles_b = slam_div_up(n_max, TILE_B), tpp = slam_div_up(n_max, ROWS_SMALL * BLOCK);
+    const long split_bound = std::min<long>((long)n_prob * std::min<long>(tiles_b, MAX_SPLIT), 1024 / tpp > 0 ? 1024 / tpp : 1);
+    const long units = std::max<long>(n_prob, split_bound);
+    return scratch_keys(1, n_max, 1, mode) * (size_t)units * sizeof(unsigned) + 256;
+}
+
 extern "C" int slam_match_hamming_batched(const uint8_t *d_desc, const int32_t *d_count, int n_max,
                                           const int32_t *d_prob_query, const int32_t *d_prob_train, int n_prob,
-                                          int norm, int mode, uint32_t *d_key1, uint32_t *d_key2, void *stream) {
+                                          int norm, int mode, double ratio, uint32_t *d_key1, uint32_t *d_key2,
+                                          void *d_workspace, size_t workspace_bytes, void *stream) {
     return slam_launch_match_batched(d_desc, d_count, n_max, d_prob_query, d_prob_train, nullptr, n_prob, norm, mode,
-                                     d_key1, d_key2, (hipStream_t)stream);
+                                     ratio, d_key1, d_key2, d_workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int slam_launch_match_batched(const uint8_t *d_desc, const int32_t *d_count, int n_max, const int32_t *d_prob_query,
                               const int32_t *d_prob_train, const int32_t *d_order, int n_prob, int norm, int mode,
-                              uint32_t *d_key1, uint32_t *d_key2, hipStream_t st) {
-    SLAM_REQUIRE(norm == SLAM_NORM_HAMMING || norm == SLAM_NORM_HAMMING2, "slam_match_hamming_batched: norm %d", norm);
-    SLAM_REQUIRE(mode == SLAM_MATCH_CROSSCHECK || mode == SLAM_MATCH_KNN2, "slam_match_hamming_batched: mode %d", mode);
-    SLAM_REQUIRE(n_max > 0 && n_max < SLAM_MAX_ROWS && n_prob >= 0, "slam_match_hamming_batched: bad sizes");
+                              double ratio, uint32_t *d_key1, uint32_t *d_key2, void *d_workspace, size_t workspace_bytes,
+                              hipStream_t st) {
+    const char *who = "slam_match_hamming_batched";
+    const int rc = check_mode(who, norm, mode);
+    if (rc) return rc;
+    SLAM_REQUIRE(n_max > 0 && n_max < SLAM_MAX_ROWS && n_prob >= 0, "%s: bad sizes", who);
     if (n_prob == 0) return SLAM_OK;
-    SLAM_REQUIRE(d_desc && d_count && d_prob_query && d_prob_train && d_key1 && (mode == SLAM_MATCH_CROSSCHECK || d_key2),
-                 "slam_match_hamming_batched: null pointer");
-    SLAM_REQUIRE(((uintptr_t)d_desc & 15) == 0, "slam_match_hamming_batched: descriptors must be 16-byte aligned");
-    const bool cross = mode == SLAM_MATCH_CROSSCHECK;
-    SLAM_HIP_CHECK(hipMemsetAsync(d_key1, 0xFF, sizeof(uint32_t) * (size_t)n_prob * n_max, st));
-    if (!cross) SLAM_HIP_CHECK(hipMemsetAsync(d_key2, 0xFF, sizeof(uint32_t) * (size_t)n_prob * n_max, st));
+    SLAM_REQUIRE(d_desc && d_count && d_prob_query && d_prob_train && d_key1 && (mode != SLAM_MATCH_KNN2 || d_key2),
+                 "%s: null pointer", who);
+    SLAM_REQUIRE(((uintptr_t)d_desc & 15) == 0, "%s: descriptors must be 16-byte aligned", who);
     MatchBatch mb{};
     mb.desc = (const uint4 *)d_desc;
     mb.count = d_count;
-    mb.prob_a = cross ? d_prob_train : d_prob_query;
-    mb.prob_b = cross ? d_prob_query : d_prob_train;
+    mb.prob_a = d_prob_query;
+    mb.prob_b = d_prob_train;
     mb.order = d_order;
     mb.n_max = n_max;
     mb.n_prob = n_prob;
-    mb.nsplit = 1;
-    mb.out1 = d_key1;
-    mb.out2 = cross ? nullptr : d_key2;
-    mb.out_stride = n_max;
-    if (cross)
-        launch_allpairs<true>(mb, n_max, norm, st);
-    else
-        launch_allpairs<false>(mb, n_max, norm, st);   // nsplit == 1: partial slot 0 is the final answer
-    SLAM_HIP_CHECK(hipGetLastError());
-    return SLAM_OK;
+    return run_match(who, mb, n_max, n_max, norm, mode, mode == SLAM_MATCH_KNN2 ? ratio : 0.0, d_key1, d_key2, n_max, n_max,
+                     (unsigned *)d_workspace, workspace_bytes, st);
 }
 
 extern "C" int slam_unpack_keys(const uint32_t *d_key, int n, int32_t *d_index, int32_t *d_distance, void *stream) {

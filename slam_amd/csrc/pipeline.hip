@@ -45,7 +45,9 @@ struct Carver {
 
 struct Buffers {
     // device
-    uint32_t *stereo_key, *temporal_key;
+    uint32_t *stereo_key, *temporal_key, *key2;
+    void *match_ws;
+    size_t match_ws_bytes;
     int32_t *setup, *prob_q, *prob_t, *pair_f0, *pair_f1, *order, *tcount, *aux;
     float *xy0, *xy1;
     double *X;
@@ -77,6 +79,10 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     b.RB = (int)(HYP_BUDGET / ROUND_QUANTUM);
     b.stereo_key = d.take<uint32_t>((Fs + Ps) * N);   // one key array: F stereo problems, then P temporal ones
     b.temporal_key = b.stereo_key ? b.stereo_key + Fs * N : nullptr;
+    const int mode = cfg ? cfg->match_mode : SLAM_MATCH_CROSSCHECK;
+    b.key2 = mode == SLAM_MATCH_KNN2 ? d.take<uint32_t>((Fs + Ps) * N) : nullptr;    // second nearest rows (kNN mode)
+    b.match_ws_bytes = slam_match_batched_workspace_bytes(F + P, n_max, mode);       // per-row nearest keys before the rule
+    b.match_ws = d.take<uint8_t>(b.match_ws_bytes);
     // per-call set-up arrays in ONE block, uploaded with one copy: problem lists, pair frames, pair seeds
     b.setup_len = 3 * (Fs + Ps) + 3 * Ps;
     b.setup = d.take<int32_t>(b.setup_len);
@@ -162,8 +168,8 @@ struct Shared {
     Mat33 K;
     Mat34 M2, Pm, Qm;
     RansacParams rp;
-    double thr;
-    int norm, N;
+    double thr, ratio;
+    int norm, N, match_mode;
 };
 
 // One workspace + one stream: a chunk of the shard goes through front() -> mid() -> back().
@@ -252,8 +258,8 @@ struct Lane {
         }
         SLAM_HIP_CHECK(hipEventRecord(ev[0], st));
         // ---- 1. matching: F stereo + P temporal problems, ONE launch over the contiguous key array ----
-        rc = slam_launch_match_batched(d_desc, d_count, N, b.prob_q, b.prob_t, b.order, F + P, sh.norm,
-                                       SLAM_MATCH_CROSSCHECK, b.stereo_key, nullptr, st);
+        rc = slam_launch_match_batched(d_desc, d_count, N, b.prob_q, b.prob_t, b.order, F + P, sh.norm, sh.match_mode,
+                                       sh.ratio, b.stereo_key, b.key2, b.match_ws, b.match_ws_bytes, st);
         if (rc) return rc;
         SLAM_HIP_CHECK(hipEventRecord(ev[1], st));
         // ---- 2. join, 3. triangulate ----
@@ -629,6 +635,9 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
     const int F = io->n_frames, P = io->n_pairs, N = io->n_max;
     SLAM_REQUIRE(F > 0 && P >= 0 && N > 0 && N % 64 == 0 && N < SLAM_MAX_ROWS, "slam_track_pairs: bad sizes F=%d P=%d n_max=%d (n_max must be a multiple of 64)", F, P, N);
     SLAM_REQUIRE(F + P <= 1 << 24, "slam_track_pairs: too many problems");
+    SLAM_REQUIRE(cfg->match_mode == SLAM_MATCH_CROSSCHECK || cfg->match_mode == SLAM_MATCH_KNN2 ||
+                     cfg->match_mode == SLAM_MATCH_CROSSCHECK_MUTUAL,
+                 "slam_track_pairs: match_mode %d unsupported", cfg->match_mode);
     if (P == 0) return SLAM_OK;
     SLAM_REQUIRE(io->d_desc && io->d_xy && io->d_count && io->h_pair_f0 && io->h_pair_f1 && io->h_pair_seed &&
                      io->d_tracked_kp && io->h_pose && io->h_stats && io->h_mask && io->d_workspace && io->h_workspace,
@@ -657,6 +666,8 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
                                          : (int)std::fmax(64.0 * cfg->max_iterations, 8.0 * cfg->fixed_iterations);
     sh.thr = cfg->acc * cfg->acc;
     sh.norm = cfg->norm ? cfg->norm : SLAM_NORM_HAMMING2;
+    sh.match_mode = cfg->match_mode;
+    sh.ratio = cfg->ratio > 0 ? cfg->ratio : 0.6;
 
     // ---- plan: the whole shard in one lane on the caller's stream, or chunks pipelined over two side streams ----
     std::vector<Chunk> chunks = plan_chunks(io, cfg);

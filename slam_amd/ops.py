@@ -12,8 +12,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (SLAM_KEY_NONE, SLAM_KEY_SHIFT, SLAM_MATCH_CROSSCHECK, SLAM_MATCH_KNN2, SLAM_NORM_HAMMING,
-                   SLAM_NORM_HAMMING2, check)
+from ._lib import (SLAM_KEY_NONE, SLAM_KEY_SHIFT, SLAM_MATCH_CROSSCHECK, SLAM_MATCH_CROSSCHECK_MUTUAL, SLAM_MATCH_KNN2,
+                   SLAM_NORM_HAMMING, SLAM_NORM_HAMMING2, check)
 
 IDX_MASK = (1 << SLAM_KEY_SHIFT) - 1
 
@@ -93,15 +93,19 @@ def unpack_keys(key: torch.Tensor):
 
 
 def match_keys_batched(desc: torch.Tensor, count: torch.Tensor, prob_q: torch.Tensor, prob_t: torch.Tensor,
-                       norm=SLAM_NORM_HAMMING2, mode=SLAM_MATCH_CROSSCHECK):
-    """desc uint8[n_img, n_max, 64], count int32[n_img], prob_q/prob_t int32[n_prob] -> keys int32[n_prob, n_max]."""
+                       norm=SLAM_NORM_HAMMING2, mode=SLAM_MATCH_CROSSCHECK, ratio=0.0):
+    """desc uint8[n_img, n_max, 64], count int32[n_img], prob_q/prob_t int32[n_prob] -> keys int32[n_prob, n_max].
+    ratio > 0 (KNN2 only): key1 keeps only the queries that pass d1 < ratio * d2 (significance_test)."""
     n_img, n_max, _ = desc.shape
     n_prob = prob_q.numel()
     key1 = torch.empty((n_prob, n_max), dtype=torch.int32, device=desc.device)
     key2 = torch.empty((n_prob, n_max), dtype=torch.int32, device=desc.device) if mode == SLAM_MATCH_KNN2 else None
+    wb = _lib.lib().slam_match_batched_workspace_bytes(n_prob, n_max, mode)
+    ws = torch.empty(wb, dtype=torch.uint8, device=desc.device)
     check(_lib.lib().slam_match_hamming_batched(_dev(desc, torch.uint8), _dev(count, torch.int32), n_max,
                                                 _dev(prob_q, torch.int32), _dev(prob_t, torch.int32), n_prob, norm, mode,
-                                                _dev(key1), _dev(key2) if key2 is not None else None, _stream()))
+                                                float(ratio), _dev(key1), _dev(key2) if key2 is not None else None,
+                                                _dev(ws), wb, _stream()))
     return key1, key2
 
 

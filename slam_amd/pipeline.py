@@ -47,6 +47,7 @@ def _track_config(cfg: HotPathConfig) -> _lib.SlamTrackConfig:
     c.M2[:] = np.asarray(cfg.M2, np.float64).reshape(12).tolist()
     c.rec_err, c.acc, c.prob, c.max_iterations = cfg.rec_err, cfg.supp_err, cfg.prob, cfg.max_iterations
     c.fixed_iterations, c.max_draws, c.norm, c.first_chunk = cfg.fixed_iterations, cfg.max_draws, cfg.norm, cfg.first_chunk
+    c.match_mode, c.ratio = cfg.match_mode(), float(cfg.ratio)
     return c
 
 

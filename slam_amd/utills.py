@@ -11,7 +11,11 @@ Differences a caller can observe, all forced by the environment:
   * `cv2.DMatch` / `cv2.KeyPoint` are replaced by the duck types of slam_amd.types;
   * the whole-movie and loop-closure drivers batch all frame pairs into one device pass, so they give every pair its
     own MT19937 stream (seeds drawn once from the global np.random state) instead of threading one global stream
-    through the pairs sequentially; the per-pair functions consume the global stream exactly like the reference.
+    through the pairs sequentially; the per-pair functions consume the global stream exactly like the reference;
+  * `match()` reads MATCH_METHOD when it is called, and the batched drivers read MATCH_METHOD / RATIO /
+    CROSSCHECK_RULE the same way, so assigning `utills.MATCH_METHOD = REGULAR_KNN` switches both APIs together (the
+    reference binds the default at import, :105, so there the assignment changes nothing);
+  * CROSSCHECK_RULE selects which of cv2.BFMatcher(crossCheck=True)'s two historical behaviours is followed.
 """
 from __future__ import annotations
 
@@ -19,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops, pipeline, tracks, trajectory
-from .config import BRUTE_FORCE, FLANN_KNN, NORM_HAMMING, NORM_HAMMING2, REGULAR_KNN, HotPathConfig
+from .config import BRUTE_FORCE, FLANN_KNN, MUTUAL, NORM_HAMMING, NORM_HAMMING2, OCV_LEGACY, REGULAR_KNN, HotPathConfig
 from .synth import K_KITTI, M1_KITTI, M2_KITTI
 from .types import (ArrayDataBase, DataBase, DMatch, Feature, Frame, KeyPoint, LazyPairFeatures, Track, dmatches_from_arrays,
                     keypoints_from_xy, keypoints_to_xy)
@@ -29,6 +33,9 @@ K, M1, M2 = K_KITTI.copy(), M1_KITTI.copy(), M2_KITTI.copy()
 RATIO = 0.6
 MATCHES_NORM = NORM_HAMMING2
 MATCH_METHOD = BRUTE_FORCE
+# which of cv2.BFMatcher(crossCheck=True)'s two historical behaviours the cross-check matcher follows (the reference
+# pins no OpenCV version; config.py / DESIGN.md section 2): OCV_LEGACY (default) or MUTUAL
+CROSSCHECK_RULE = OCV_LEGACY
 PNP_NUM_PTS = 4
 SUPP_ERR = 2
 REC_ERR = 2
@@ -88,7 +95,8 @@ def _match_arrays(img1_dsc, img2_dsc, norm, mode):
 def bf_matching(metric, img1_dsc, img2_dsc, crossCheck=True, sort=True):
     """:57-70.  cv2.BFMatcher(metric, crossCheck).match: list of DMatch in query order, or sorted by distance."""
     if crossCheck:
-        idx, dist, _, _ = _match_arrays(img1_dsc, img2_dsc, metric, _lib.SLAM_MATCH_CROSSCHECK)
+        mode = _lib.SLAM_MATCH_CROSSCHECK_MUTUAL if CROSSCHECK_RULE == MUTUAL else _lib.SLAM_MATCH_CROSSCHECK
+        idx, dist, _, _ = _match_arrays(img1_dsc, img2_dsc, metric, mode)
     else:
         if len(img2_dsc) == 0:
             return []
@@ -125,8 +133,10 @@ def significance_test(matches, ratio):
     return pass_test, failed_test
 
 
-def match(img1_dsc, img2_dsc, method=MATCH_METHOD):
-    """:105-119.  Default: cross-check brute force under MATCHES_NORM, unsorted, as a numpy object array."""
+def match(img1_dsc, img2_dsc, method=None):
+    """:105-119.  Default (method = MATCH_METHOD): cross-check brute force under MATCHES_NORM, unsorted, as a numpy
+    object array."""
+    method = MATCH_METHOD if method is None else method
     if method == BRUTE_FORCE:
         return np.array(bf_matching(MATCHES_NORM, img1_dsc, img2_dsc, sort=False), dtype=object)
     if method == REGULAR_KNN:
@@ -521,7 +531,10 @@ def compute_trans_between_cur_to_next(left0_kpts, left0_dsc, right0_kpts, pair0_
 
 
 def _hot_path_config() -> HotPathConfig:
-    return HotPathConfig(K=K, M1=M1, M2=M2, norm=MATCHES_NORM, rec_err=float(REC_ERR), supp_err=float(SUPP_ERR))
+    """The module constants as the batched drivers' configuration: the whole-movie and loop-closure drivers match the
+    way match() does (MATCH_METHOD, RATIO, CROSSCHECK_RULE), as in the reference, where both go through match()."""
+    return HotPathConfig(K=K, M1=M1, M2=M2, norm=MATCHES_NORM, rec_err=float(REC_ERR), supp_err=float(SUPP_ERR),
+                         match_method=MATCH_METHOD, ratio=float(RATIO), crosscheck_rule=CROSSCHECK_RULE)
 
 
 def _source_arrays(frames):

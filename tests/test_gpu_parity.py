@@ -24,27 +24,36 @@ def dev(a, dtype=None):
     return t.cuda()
 
 
-def gpu_crosscheck(q, t, norm):
-    k1, _ = ops.match_keys(dev(ops.pad_descriptors(q)), dev(ops.pad_descriptors(t)), norm, _lib.SLAM_MATCH_CROSSCHECK)
+def gpu_crosscheck(q, t, norm, mutual=False):
+    mode = _lib.SLAM_MATCH_CROSSCHECK_MUTUAL if mutual else _lib.SLAM_MATCH_CROSSCHECK
+    k1, _ = ops.match_keys(dev(ops.pad_descriptors(q)), dev(ops.pad_descriptors(t)), norm, mode)
     idx, dist = ops.unpack_keys(k1)
     idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
     qi = np.nonzero(idx >= 0)[0].astype(np.int32)
     return qi, idx[qi], dist[qi]
 
 
+@pytest.mark.parametrize("mutual", [False, True], ids=["ocv_legacy", "mutual"])
 @pytest.mark.parametrize("norm", [orc.NORM_HAMMING2, orc.NORM_HAMMING])
 @pytest.mark.parametrize("shape", [(1, 1), (1, 300), (300, 1), (64, 64), (129, 513), (1000, 777), (2000, 1987), (3000, 5000)])
-def test_crosscheck_match_bit_exact(norm, shape):
+def test_crosscheck_match_bit_exact(norm, shape, mutual):
+    """Both cross-check rules cv2.BFMatcher(crossCheck=True) has had (utills.py:57-70; SLAM_MATCH_CROSSCHECK = the
+    one-directional legacy rule, SLAM_MATCH_CROSSCHECK_MUTUAL = mutual nearest rows) against the C oracle, on
+    tie-heavy rows where first-minimum / lowest-row tie-breaks decide."""
     rng = np.random.default_rng(shape[0] * 7919 + shape[1] + norm)
     nq, nt = shape
     # few distinct byte values -> many equal distances -> tie-breaks matter
     q = rng.integers(0, 4, (nq, 61), dtype=np.uint8)
     t = rng.integers(0, 4, (nt, 61), dtype=np.uint8)
     t[: min(nq, nt) // 2] = q[: min(nq, nt) // 2]          # exact duplicates (distance 0 ties)
-    want = c_oracle.match_crosscheck(q, t, norm)
-    got = gpu_crosscheck(q, t, norm)
+    want = c_oracle.match_crosscheck(q, t, norm, mutual=mutual)
+    got = gpu_crosscheck(q, t, norm, mutual)
     for a, b in zip(want, got):
         assert np.array_equal(a, b)
+    if mutual and min(shape) >= 64:
+        # the mutual rule keeps a subset of the legacy rule's pairs, and strictly fewer on data like this
+        legacy = gpu_crosscheck(q, t, norm)
+        assert {*zip(got[0].tolist(), got[1].tolist())} < {*zip(legacy[0].tolist(), legacy[1].tolist())}
 
 
 def test_crosscheck_match_random_full_bytes():
@@ -77,11 +86,29 @@ def test_crosscheck_match_row_indices_beyond_16_bits(shape):
     assert max(max(got[0]), max(got[1])) > 65535
 
 
-def test_match_empty_inputs():
+@pytest.mark.parametrize("mutual", [False, True], ids=["ocv_legacy", "mutual"])
+def test_match_empty_inputs(mutual):
     q = np.zeros((0, 61), np.uint8)
     t = np.random.default_rng(0).integers(0, 256, (10, 61), dtype=np.uint8)
-    assert len(gpu_crosscheck(q, t, orc.NORM_HAMMING2)[0]) == 0
-    assert len(gpu_crosscheck(t, q, orc.NORM_HAMMING2)[0]) == 0
+    assert len(gpu_crosscheck(q, t, orc.NORM_HAMMING2, mutual)[0]) == 0
+    assert len(gpu_crosscheck(t, q, orc.NORM_HAMMING2, mutual)[0]) == 0
+
+
+def test_crosscheck_more_query_rows_than_lds_slots():
+    """Above 8192 query rows the legacy rule's per-query slots no longer fit the resolve kernel's LDS array and it
+    scatters with global atomics instead: same lists as the oracle on both sides of the limit, both rules."""
+    rng = np.random.default_rng(8)
+    for nq, nt in ((8192, 3000), (8193, 3000), (9000, 9100)):
+        q = rng.integers(0, 256, (nq, 61), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, 61), dtype=np.uint8)
+        t[:1000] = q[nq - 1000:] ^ (rng.random((1000, 61)) < 0.02).astype(np.uint8)
+        for mutual in (False, True):
+            want = c_oracle.match_crosscheck_w64(c_oracle.pad64(q), c_oracle.pad64(t), orc.NORM_HAMMING2) if not mutual \
+                else c_oracle.match_crosscheck(q, t, orc.NORM_HAMMING2, mutual=True)
+            got = gpu_crosscheck(q, t, orc.NORM_HAMMING2, mutual)
+            assert len(want[0]) >= 1000
+            for a, b in zip(want, got):
+                assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("norm", [orc.NORM_HAMMING2, orc.NORM_HAMMING])
@@ -163,11 +190,13 @@ def _small_sequence(n_frames=5, n_features=300, seed=3):
     return seq, desc, xy, count
 
 
-@pytest.mark.parametrize("mode", ["crosscheck", "knn2"])
+@pytest.mark.parametrize("mode", ["crosscheck", "knn2", "mutual"])
 def test_batched_matcher_rows_per_lane_variants_agree(mode):
-    """The batched matcher runs 4 rows per lane when the grid fills the chip and 2 rows per lane for a small batch
-    (launch_allpairs).  The same six problems go through both: alone (2 rows) and repeated 70 times in one batch of 420
-    problems x 2 tiles (4 rows); keys must be identical, and equal to the single-problem entry point's."""
+    """The batched matcher runs 4 rows per lane when the grid fills the chip, and for a batch too small for that 2 rows
+    per lane with the scanned image split over workgroups (a loop-closure call with a handful of candidates,
+    utills.py:1118-1146).  The same six problems go through every plan: each alone (most splits), the six together
+    (fewer splits), and repeated 70 times in one batch of 420 problems x 2 tiles (4 rows, no split); keys must be
+    identical, equal to the single-problem entry point's, and for the cross-check rules equal to the C oracle's."""
     rng = np.random.default_rng(17)
     n_max = 2048
     counts = np.array([1970, 2048, 1, 1025, 700, 0, 1500, 64], np.int32)
@@ -177,9 +206,21 @@ def test_batched_matcher_rows_per_lane_variants_agree(mode):
     desc[1, :900, :61] = desc[0, :900, :61]
     pq = np.array([0, 1, 2, 3, 6, 5], np.int32)
     pt = np.array([1, 0, 3, 4, 7, 6], np.int32)
-    m = _lib.SLAM_MATCH_CROSSCHECK if mode == "crosscheck" else _lib.SLAM_MATCH_KNN2
+    m = {"crosscheck": _lib.SLAM_MATCH_CROSSCHECK, "knn2": _lib.SLAM_MATCH_KNN2, "mutual": _lib.SLAM_MATCH_CROSSCHECK_MUTUAL}[mode]
     d_desc, d_count = dev(desc), dev(counts)
     small = ops.match_keys_batched(d_desc, d_count, dev(pq), dev(pt), mode=m)
+    for k in range(len(pq)):                                                  # one problem per call: B split the most
+        alone = ops.match_keys_batched(d_desc, d_count, dev(pq[k:k + 1]), dev(pt[k:k + 1]), mode=m)
+        for a, b in zip(small, alone):
+            if a is not None:
+                assert np.array_equal(a.cpu().numpy()[k], b.cpu().numpy()[0])
+    if mode != "knn2":
+        idx, dist = (x.cpu().numpy() for x in ops.unpack_keys(small[0]))
+        for k in range(len(pq)):
+            nq, nt = counts[pq[k]], counts[pt[k]]
+            wq, wt, wd = c_oracle.match_crosscheck(desc[pq[k], :nq, :61], desc[pt[k], :nt, :61], orc.NORM_HAMMING2, mutual=mode == "mutual")
+            got_q = np.nonzero(idx[k] >= 0)[0]
+            assert np.array_equal(got_q, wq) and np.array_equal(idx[k][got_q], wt) and np.array_equal(dist[k][got_q], wd)
     big = ops.match_keys_batched(d_desc, d_count, dev(np.tile(pq, 70)), dev(np.tile(pt, 70)), mode=m)
     for a, b in zip(small, big):
         if a is None:
@@ -195,6 +236,33 @@ def test_batched_matcher_rows_per_lane_variants_agree(mode):
         for a, b in zip(small, one):
             if a is not None:
                 assert np.array_equal(a.cpu().numpy()[k, :nq], b.cpu().numpy())
+
+
+def test_batched_knn_with_ratio_test_on_the_device():
+    """match(..., REGULAR_KNN) for a whole batch (utills.py:112-119): two nearest rows + significance_test
+    `d1 < RATIO * d2` in float64 applied by the resolve kernel; held to the oracle incl. exact ties of the comparison."""
+    q, t, plan = _ratio_case()
+    rng = np.random.default_rng(1)
+    imgs = [q, t, rng.integers(0, 8, (100, 61), dtype=np.uint8), rng.integers(0, 8, (120, 61), dtype=np.uint8),
+            rng.integers(0, 8, (1, 61), dtype=np.uint8)]
+    n_max = (max(len(i) for i in imgs) + 63) // 64 * 64
+    desc = np.zeros((len(imgs), n_max, 64), np.uint8)
+    counts = np.array([len(i) for i in imgs], np.int32)
+    for k, im in enumerate(imgs):
+        desc[k, :len(im), :61] = im
+    pq, pt = np.array([0, 2, 3, 2], np.int32), np.array([1, 3, 2, 4], np.int32)          # last: a single train row
+    for ratio in (0.6, 0.8, 1.0):
+        k1, k2 = ops.match_keys_batched(dev(desc), dev(counts), dev(pq), dev(pt), mode=_lib.SLAM_MATCH_KNN2, ratio=ratio)
+        i1, d1 = (x.cpu().numpy() for x in ops.unpack_keys(k1))
+        for k in range(len(pq)):
+            a, b = imgs[pq[k]], imgs[pt[k]]
+            got_q = np.nonzero(i1[k] >= 0)[0]
+            if len(b) < 2:
+                assert len(got_q) == 0                     # no second neighbour: nothing can pass (the reference cannot unpack it)
+                continue
+            wq, wt, wd = orc.knn_ratio_match(a, b, orc.NORM_HAMMING2, ratio)
+            assert np.array_equal(got_q, wq) and np.array_equal(i1[k][got_q], wt) and np.array_equal(d1[k][got_q], wd)
+        assert 0 < (i1[0] >= 0).sum() < len(q)
 
 
 def test_batched_match_and_join_bit_exact():
@@ -472,6 +540,47 @@ def test_full_pipeline_against_oracle_sequence():
         assert err <= REL_TOL, (p, err)
         gt = seq.gt_relative(p + 1)
         assert np.abs(res.pose[p] - gt).max() < 0.05
+
+
+@pytest.mark.parametrize("how", ["mutual", "knn_ratio"])
+def test_full_pipeline_other_match_methods_against_oracle(how):
+    """The shard pipeline matches the way match() does (utills.py:105-119): with the mutual cross-check rule, and with
+    REGULAR_KNN (two nearest + ratio 0.6, no cross-check: several left0 key-points may land on one left1 key-point).
+    Tracked sets bit-exact against the oracle run with the same matcher; masks and counts equal; poses within REL_TOL."""
+    from slam_amd.config import MUTUAL, REGULAR_KNN, HotPathConfig
+    from slam_amd.pipeline import ShardTracker, consecutive_pairs
+    seq, desc, xy, count = _small_sequence(n_frames=6, n_features=320, seed=9)
+    F, _, n_max, _ = desc.shape
+    cfg = HotPathConfig(crosscheck_rule=MUTUAL) if how == "mutual" else HotPathConfig(match_method=REGULAR_KNN)
+    matcher = orc.bf_match_mutual if how == "mutual" else orc.knn_ratio_match
+    f0, f1 = consecutive_pairs(F)
+    seeds = 1000 + np.arange(F - 1)
+    args = (dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)), f0, f1, seeds)
+    res = ShardTracker(F, F - 1, n_max, cfg).run(*args)
+    base = ShardTracker(F, F - 1, n_max).run(*args)
+    kp = res.tracked_kp.cpu().numpy()
+
+    def frame(i):
+        n0, n1 = count[i]
+        return dict(dsc_l=desc[i, 0, :n0, :61], dsc_r=desc[i, 1, :n1, :61], xy_l=xy[i, 0, :n0], xy_r=xy[i, 1, :n1])
+
+    for p in range(F - 1):
+        np.random.seed(int(seeds[p]))
+        st = {}
+        with np.errstate(all="ignore"):
+            want = orc.track_pair(frame(p), frame(p + 1), stats=st, matcher=matcher)
+        T = len(want["kp"])
+        assert res.stats[p, 0] == T and T > 50
+        assert np.array_equal(kp[p, :T], want["kp"])
+        assert res.stats[p, 2] == st["iterations"] and res.stats[p, 3] == st["draws"] and res.stats[p, 4] == st["best_draw"]
+        assert np.array_equal(res.mask[p, :T], want["mask"]) and not res.mask[p, T:].any()
+        err = np.linalg.norm(res.pose[p] - want["T"]) / np.linalg.norm(want["T"])
+        assert err <= REL_TOL, (p, err)
+    # the method really changes the match lists on this data (stats columns 6, 7: stereo / temporal matches per pair;
+    # the mutual rule keeps a subset of the legacy rule's pairs, most of the others die in the 4-view join anyway)
+    assert not np.array_equal(res.stats[:, 6:8], base.stats[:, 6:8])
+    if how == "mutual":
+        assert (res.stats[:, 6:8] <= base.stats[:, 6:8]).all()
 
 
 def test_longer_sequence_equals_oracle_wherever_no_draw_repeats_its_fourth_index():
