@@ -597,27 +597,16 @@ def run_stress(args, rk: Rank):
     rk.emit(out)
 
 
-def loop_candidates(F, seed=3):
-    """configs[4]: every frame from 6 on against 5 candidate frames: 2 revisits (f-2, f-5) + 3 random earlier frames."""
-    rng = np.random.default_rng(seed)
-    cur, cand = [], []
-    for f in range(6, F):
-        for c in (f - 2, f - 5, *rng.integers(0, max(1, f - 5), 3)):
-            cand.append(int(c))
-            cur.append(f)
-    return np.array(cand, np.int32), np.array(cur, np.int32)
-
-
 def run_loops(args, rk: Rank):
     """BASELINE configs[4]: loop-closure candidate validation, 3450 frames x 5 candidates each, one device pass."""
     torch = rk.torch
     from slam_amd import pipeline
-    from slam_amd.synth import SynthConfig, SynthSequence
+    from slam_amd.synth import SynthConfig, SynthSequence, loop_candidate_pairs
     F = args.frames
     scfg = SynthConfig(n_frames=F, n_features=args.features, seed=args.seed)
     desc, xy, count = SynthSequence(scfg).frames(0, F)
     n_max = scfg.n_max
-    f0, f1 = loop_candidates(F)
+    f0, f1 = loop_candidate_pairs(F)
     P = len(f0)
     trk = pipeline.ShardTracker(F, P, n_max, hot_path_config(args), n_chunks=1)
     dev_args = (torch.from_numpy(desc.reshape(2 * F, n_max, 64)).cuda(), torch.from_numpy(xy.reshape(2 * F, n_max, 2)).cuda(),

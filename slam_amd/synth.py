@@ -62,6 +62,19 @@ def stress_config(n_frames: int = 40, n_features: int = 8000, seed: int = 5) -> 
                        mismatch_frac=0.05, gross_frac=0.27, gross_sigma=15.0, gross_x_only=True, ragged=31)
 
 
+def loop_candidate_pairs(n_frames: int, seed: int = 3):
+    """BASELINE configs[4] / SURVEY 8(d) "Config 5": every frame from 6 on against 5 candidate frames, 2 true revisits
+    (f - 2, f - 5) + 3 random earlier frames.  Returns (candidate frame, current frame) int32 arrays: the candidate is
+    "frame 0" of the pair and the current frame "frame 1" (utils/utills.py:1128-1134)."""
+    rng = np.random.default_rng(seed)
+    cur, cand = [], []
+    for f in range(6, n_frames):
+        for c in (f - 2, f - 5, *rng.integers(0, max(1, f - 5), 3)):
+            cand.append(int(c))
+            cur.append(f)
+    return np.array(cand, np.int32), np.array(cur, np.int32)
+
+
 def _rot_y(a):
     c, s = np.cos(a), np.sin(a)
     return np.array([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]])
