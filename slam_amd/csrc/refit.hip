@@ -9,6 +9,8 @@
 // within 4 px, so it lies in the same basin), with a left-multiplied se(3) increment instead of OpenCV's
 // (rvec, tvec) parameters.  Same minimiser, hence the 1e-5 relative pose tolerance of the parity tests;
 // OpenCV itself is absent, so this is "parity unpinned" against cv2 and pinned against oracle/slam_oracle.py.
+#include <algorithm>
+
 #include "common.h"
 #include "jacobi.h"   // rcp_nr
 #include "kernels.h"
@@ -110,10 +112,19 @@ constexpr int MAX_EVAL = 60;
 #define SLAM_REFIT_STEP2 1e-18
 #endif
 
+// LDS: the supporters of the pair, compacted once (x, y, z as doubles + the left observation in its own type: 32 bytes per
+// supporter for float32 key-point rows), when there are at most `cap` of them; every Levenberg-Marquardt pass then reads them from LDS with all
+// lanes busy.  (Round 1 re-read the tracked points from global memory in every pass, masked: ~15 passes x 48 KB per
+// pair = 1.78 GB of fabric reads per launch for 0.2 GB of data.)  A pair with more supporters than `cap` walks global
+// memory as before.
 template <typename XY4>
 __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, const XY4 *xy1, const int *count,
                                                    int seg_stride, const unsigned long long *mask_words,
-                                                   const double *pose0, double *pose_out, uint8_t *status) {
+                                                   const double *pose0, double *pose_out, uint8_t *status, int cap) {
+    extern __shared__ double lds[];
+    using UV = decltype(XY4::x);             // observations keep the caller's type: float32 key-point rows or float64
+    double *sx = lds, *sy = lds + cap, *sz = lds + 2 * cap;
+    UV *su = (UV *)(lds + 3 * cap), *sv = su + cap;
     const int seg = blockIdx.x, lane = threadIdx.x;
     const int n = count[seg];
     const int words = seg_stride / 64;
@@ -141,14 +152,14 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
         P.t[i] = pose0[(size_t)seg * 12 + i * 4 + 3];
     }
 
-    // Both passes walk the points four wave-steps (256 points) at a time with the loads of all four issued before
-    // the arithmetic: one wave per pair is latency bound, and this exposes one memory round trip where there were
-    // four.  Every lane still adds its points in ascending order, so the sums are the bits they were before.
     constexpr int UN = 4;
-    auto cost_of = [&](const Pose &Q) {
-        double c = 0;
+    const bool in_lds = supp <= cap;          // wave-uniform
+    if (in_lds) {
+        // ordered compaction, four wave-steps of loads in flight at a time
+        int base_out = 0;
         for (int base = 0; base < n; base += 64 * UN) {
-            double px[UN], py[UN], pz[UN], ou[UN], ov[UN];
+            double px[UN], py[UN], pz[UN];
+            UV ou[UN], ov[UN];
             bool ok[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
@@ -157,21 +168,61 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
                 if (ok[u]) {
                     px[u] = Xs[i * 3], py[u] = Xs[i * 3 + 1], pz[u] = Xs[i * 3 + 2];
                     const XY4 o = obs[i];
-                    ou[u] = (double)o.x, ov[u] = (double)o.y;
+                    ou[u] = o.x, ov[u] = o.y;
                 }
             }
 #pragma unroll
-            for (int u = 0; u < UN; ++u)
+            for (int u = 0; u < UN; ++u) {
+                const unsigned long long bal = __ballot(ok[u]);
                 if (ok[u]) {
-                    const double x = px[u], y = py[u], z = pz[u];
-                    const double xc = Q.R[0][0] * x + Q.R[0][1] * y + Q.R[0][2] * z + Q.t[0];
-                    const double yc = Q.R[1][0] * x + Q.R[1][1] * y + Q.R[1][2] * z + Q.t[1];
-                    const double zc = Q.R[2][0] * x + Q.R[2][1] * y + Q.R[2][2] * z + Q.t[2];
-                    const double iz = rcp_nr(zc);      // refined hardware reciprocal: the minimiser does not depend on the last ulp
-                    const double ru = fx * xc * iz + cx - ou[u], rv = fy * yc * iz + cy - ov[u];
-                    c += ru * ru + rv * rv;
+                    const int o = base_out + __popcll(bal & ((1ull << lane) - 1ull));
+                    sx[o] = px[u], sy[o] = py[u], sz[o] = pz[u];
+                    su[o] = ou[u], sv[o] = ov[u];
                 }
+                base_out += __popcll(bal);
+            }
         }
+        __syncthreads();
+    }
+
+    // body(x, y, z, u, v) for every supporter; every lane adds its points in a fixed order, so a call's sums are
+    // reproducible bit for bit
+    auto for_supporters = [&](auto body) {
+        if (in_lds) {
+            for (int i = lane; i < supp; i += 64) body(sx[i], sy[i], sz[i], (double)su[i], (double)sv[i]);
+        } else {
+            // walk the tracked points four wave-steps (256 points) at a time with the loads of all four issued before
+            // the arithmetic: one wave per pair is latency bound
+            for (int base = 0; base < n; base += 64 * UN) {
+                double px[UN], py[UN], pz[UN], ou[UN], ov[UN];
+                bool ok[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int i = base + u * 64 + lane;
+                    ok[u] = i < n && ((mw[i >> 6] >> (i & 63)) & 1ull);
+                    if (ok[u]) {
+                        px[u] = Xs[i * 3], py[u] = Xs[i * 3 + 1], pz[u] = Xs[i * 3 + 2];
+                        const XY4 o = obs[i];
+                        ou[u] = (double)o.x, ov[u] = (double)o.y;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u)
+                    if (ok[u]) body(px[u], py[u], pz[u], ou[u], ov[u]);
+            }
+        }
+    };
+
+    auto cost_of = [&](const Pose &Q) {
+        double c = 0;
+        for_supporters([&](double x, double y, double z, double ou, double ov) {
+            const double xc = Q.R[0][0] * x + Q.R[0][1] * y + Q.R[0][2] * z + Q.t[0];
+            const double yc = Q.R[1][0] * x + Q.R[1][1] * y + Q.R[1][2] * z + Q.t[1];
+            const double zc = Q.R[2][0] * x + Q.R[2][1] * y + Q.R[2][2] * z + Q.t[2];
+            const double iz = rcp_nr(zc);      // refined hardware reciprocal: the minimiser does not depend on the last ulp
+            const double ru = fx * xc * iz + cx - ou, rv = fy * yc * iz + cy - ov;
+            c += ru * ru + rv * rv;
+        });
         return wave_sum(c);
     };
 
@@ -186,42 +237,25 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
         for (int k = 0; k < 21; ++k) H[k] = 0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) g[k] = 0;
-        for (int base = 0; base < n; base += 64 * UN) {
-            double px[UN], py[UN], pz[UN], ou[UN], ov[UN];
-            bool ok[UN];
+        for_supporters([&](double x, double y, double z, double ou, double ov) {
+            const double xc = P.R[0][0] * x + P.R[0][1] * y + P.R[0][2] * z + P.t[0];
+            const double yc = P.R[1][0] * x + P.R[1][1] * y + P.R[1][2] * z + P.t[1];
+            const double zc = P.R[2][0] * x + P.R[2][1] * y + P.R[2][2] * z + P.t[2];
+            const double iz = rcp_nr(zc);
+            const double ru = fx * xc * iz + cx - ou, rv = fy * yc * iz + cy - ov;
+            // d(u,v)/dXc
+            const double ux = fx * iz, uz = -fx * xc * iz * iz, vy = fy * iz, vz = -fy * yc * iz * iz;
+            // dXc/d(omega) = -[Xc]x, dXc/d(upsilon) = I
+            const double Ju[6] = {uz * yc, ux * zc - uz * xc, -ux * yc, ux, 0.0, uz};
+            const double Jv[6] = {-vy * zc + vz * yc, -vz * xc, vy * xc, 0.0, vy, vz};
+            int k = 0;
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int i = base + u * 64 + lane;
-                ok[u] = i < n && ((mw[i >> 6] >> (i & 63)) & 1ull);
-                if (ok[u]) {
-                    px[u] = Xs[i * 3], py[u] = Xs[i * 3 + 1], pz[u] = Xs[i * 3 + 2];
-                    const XY4 o = obs[i];
-                    ou[u] = (double)o.x, ov[u] = (double)o.y;
-                }
+            for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                for (int b = a; b < 6; ++b) H[k++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+                g[a] += Ju[a] * ru + Jv[a] * rv;
             }
-#pragma unroll
-            for (int u = 0; u < UN; ++u)
-                if (ok[u]) {
-                    const double x = px[u], y = py[u], z = pz[u];
-                    const double xc = P.R[0][0] * x + P.R[0][1] * y + P.R[0][2] * z + P.t[0];
-                    const double yc = P.R[1][0] * x + P.R[1][1] * y + P.R[1][2] * z + P.t[1];
-                    const double zc = P.R[2][0] * x + P.R[2][1] * y + P.R[2][2] * z + P.t[2];
-                    const double iz = rcp_nr(zc);
-                    const double ru = fx * xc * iz + cx - ou[u], rv = fy * yc * iz + cy - ov[u];
-                    // d(u,v)/dXc
-                    const double ux = fx * iz, uz = -fx * xc * iz * iz, vy = fy * iz, vz = -fy * yc * iz * iz;
-                    // dXc/d(omega) = -[Xc]x, dXc/d(upsilon) = I
-                    const double Ju[6] = {uz * yc, ux * zc - uz * xc, -ux * yc, ux, 0.0, uz};
-                    const double Jv[6] = {-vy * zc + vz * yc, -vz * xc, vy * xc, 0.0, vy, vz};
-                    int k = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                        for (int b = a; b < 6; ++b) H[k++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
-                        g[a] += Ju[a] * ru + Jv[a] * rv;
-                    }
-                }
-        }
+        });
 #pragma unroll
         for (int k = 0; k < 21; ++k) H[k] = wave_sum(H[k]);
 #pragma unroll
@@ -279,6 +313,36 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
     }
 }
 
+// supporters per pair held in LDS (32 bytes each).  Many pairs: 1536 (48 KB, three pairs per CU keep the launch's
+// occupancy); few pairs (the stress configuration's 8k-feature images): up to 4096 (128 KB), occupancy being no concern
+#ifndef SLAM_REFIT_CAP
+#define SLAM_REFIT_CAP 1536
+#endif
+template <typename XY4>
+int launch_refit_t(const Mat33 &K, const double *d_X, const XY4 *d_xy1, const int32_t *d_count, int n_seg, int seg_stride,
+                   const uint64_t *d_mask_words, const double *d_pose0, double *d_pose, uint8_t *d_status, hipStream_t st) {
+    const size_t per = 24 + 2 * sizeof(decltype(XY4::x));       // LDS bytes per supporter
+    int cap = std::min(seg_stride, n_seg <= 256 ? 4096 : SLAM_REFIT_CAP);
+    size_t lds_bytes = (size_t)cap * per;
+    if (lds_bytes > 64 * 1024) {
+        static bool raised = false, raise_ok = false;
+        if (!raised) {
+            raise_ok = hipFuncSetAttribute((const void *)refit_kernel<XY4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024) == hipSuccess;
+            (void)hipGetLastError();
+            raised = true;
+        }
+        if (!raise_ok) {
+            cap = (int)(64 * 1024 / per);
+            lds_bytes = (size_t)cap * per;
+        }
+    }
+    hipLaunchKernelGGL(refit_kernel<XY4>, dim3(n_seg), dim3(64), lds_bytes, st, K, d_X, d_xy1, d_count, seg_stride,
+                       (const unsigned long long *)d_mask_words, d_pose0, d_pose, d_status, cap);
+    SLAM_HIP_CHECK(hipGetLastError());
+    return SLAM_OK;
+}
+
 }  // namespace
 
 int slam_launch_refit(const Mat33 &K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count, int n_seg,
@@ -287,13 +351,8 @@ int slam_launch_refit(const Mat33 &K, const double *d_X, const void *d_xy1, int 
     if (n_seg <= 0) return SLAM_OK;
     SLAM_REQUIRE(seg_stride % 64 == 0, "slam_refit_pnp: seg_stride must be a multiple of 64");
     if (xy_f64)
-        hipLaunchKernelGGL(refit_kernel<double4>, dim3(n_seg), dim3(64), 0, st, K, d_X, (const double4 *)d_xy1, d_count,
-                           seg_stride, (const unsigned long long *)d_mask_words, d_pose0, d_pose, d_status);
-    else
-        hipLaunchKernelGGL(refit_kernel<float4>, dim3(n_seg), dim3(64), 0, st, K, d_X, (const float4 *)d_xy1, d_count,
-                           seg_stride, (const unsigned long long *)d_mask_words, d_pose0, d_pose, d_status);
-    SLAM_HIP_CHECK(hipGetLastError());
-    return SLAM_OK;
+        return launch_refit_t(K, d_X, (const double4 *)d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status, st);
+    return launch_refit_t(K, d_X, (const float4 *)d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status, st);
 }
 
 extern "C" int slam_refit_pnp(const double *h_K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count,
