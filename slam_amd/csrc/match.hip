@@ -5,7 +5,7 @@
 //
 // Shape of the work: integer VALU (xor / or / popcount), not a GEMM and not HBM bound
 // (2000 x 2000 rows x 64 B = 256 KB in, 35 lane-ops per row pair).  Mapping:
-//   - every lane owns ROWS "A" rows in registers (64 VGPRs), pre-transformed so that a
+//   - every lane owns ROWS "A" rows in registers (16 VGPRs each), pre-transformed so that a
 //     NORM_HAMMING2 distance over 64 bytes costs 8 x (v_xor, v_bitop3 "(a^b)|c", v_bcnt accumulate):
 //     each dword pair (w0, w1) is re-packed into E = even bits of w0 | even bits of w1 << 1 and
 //     O = odd bits of w0 >> 1 | odd bits of w1, so a 2-bit cell differs iff (Ea^Eb)|(Oa^Ob) has
@@ -18,9 +18,9 @@
 //     skipped for most B rows.
 //   - a wavefront owns 64 * ROWS consecutive A rows; the last wavefront of an image, whose trailing row slots are
 //     empty, runs a variant compiled for fewer rows.
-//   - the 32 distance chains of a B row (4 rows x 8 words) are issued side by side, one step of all of them at a
-//     time (32 x v_xor, 32 x v_bitop3, 32 x v_bcnt): the order matters by 15 % on this part.
-//   - tile shape (4 rows/lane, 256 threads, 128-row B tiles) chosen by a sweep on the MI355X.
+//   - the 16 distance chains of a B row (2 rows x 8 words) are issued side by side, one step of all of them at a
+//     time (16 x v_xor, 16 x v_bitop3, 16 x v_bcnt): the order matters by 15 % on this part.
+//   - tile shape (2 rows/lane, 256 threads, 128-row B tiles) chosen by sweeps on the MI355X.
 //   - the all-pairs kernel only finds, for every A row, its nearest (kNN: two nearest) B row, and writes those keys
 //     with plain stores; a small second kernel (resolve_kernel, one workgroup per problem) merges the B splits and
 //     applies the matching rule on them:
@@ -35,6 +35,8 @@
 //   - a batch of few problems (a loop-closure call with 3-5 candidates) splits B over blockIdx.y until the grid fills
 //     the chip; the resolve kernel merges the splits.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 
@@ -44,7 +46,7 @@
 namespace {
 
 #ifndef SLAM_ROWS
-#define SLAM_ROWS 4
+#define SLAM_ROWS 2
 #endif
 #ifndef SLAM_BLOCK
 #define SLAM_BLOCK 256
@@ -141,8 +143,7 @@ __device__ __forceinline__ void top2_insert(unsigned &m1, unsigned &m2, unsigned
 }
 
 // TOP2: keep the second best too (kNN mode); the cross-check rules need only the nearest row.
-// RW = A rows per lane: ROWS (4) where the grid fills the chip, 2 for a batch of few problems (twice as many
-// wavefronts for the same work, see launch_allpairs).
+// RW = A rows per lane (ROWS = 2 in the shipped library; 1, 3, 4 exist in tuning builds, see plan_grid).
 template <bool NORM2, bool TOP2, int RW>
 __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
     __shared__ uint4 tile[2][TILE_B * 4];
@@ -456,10 +457,10 @@ __global__ void unpack_keys_kernel(const unsigned *key, int n, int *index, int *
     distance[i] = k == NONE ? INT32_MAX : (int)(k >> SLAM_KEY_SHIFT);
 }
 
-// Workgroups the chip holds at once: 256 CUs x 3 (139 VGPRs = 3 wavefronts per SIMD, 4 wavefronts per workgroup).
-constexpr unsigned CHIP_WORKGROUPS = 768;
-constexpr int ROWS_SMALL = 2;
 constexpr int MAX_SPLIT = 64;
+// a plan that splits B launches at most this many workgroups (plan_grid: the target, rounded up by less than one
+// split's worth of A tiles, i.e. less than twice the target)
+constexpr long PLAN_MAX_WORKGROUPS = 2 * 7000;
 
 template <int RW>
 void launch_allpairs_rows(MatchBatch mb, int a_rows, int norm, hipStream_t st) {
@@ -480,29 +481,38 @@ void launch_allpairs_rows(MatchBatch mb, int a_rows, int norm, hipStream_t st) {
     }
 }
 
-// rows per lane for a grid of n_prob problems with a_rows A rows each: 4 where that fills the chip (9 % faster at
-// full load, DESIGN.md tile sweep), else 2 (twice the wavefronts for the same distances)
-bool small_grid(int n_prob, int a_rows) {
-    return ROWS > ROWS_SMALL && (unsigned)slam_div_up(a_rows, TILE_A) * (unsigned)n_prob < CHIP_WORKGROUPS;
+// How a batch of n_prob problems of a_rows x b_rows is laid over the chip: A rows per lane and B splits.
+// Measured on the MI355X (tools/sweep_grid_plan.py, profiles/r2_matcher_grid_plan_sweep.txt):
+//   - 2 rows per lane (79 VGPRs, 6 wavefronts per SIMD) beats 4 rows per lane (139 VGPRs, 3 per SIMD) at every batch
+//     size now that the instruction order inside a B row is pinned: 14.0 against 15.5 ms for the 3450-frame shard,
+//     1.95 against 2.19 ms for an eighth of it.  (Round 1 chose 4 rows on a sweep made before the order was pinned.)
+//   - a grid of fewer than ~7000 workgroups leaves part of the chip idle at its ragged end: B is split until there
+//     are about that many (at most 16 splits, each at least one B tile); the resolve kernel merges the splits.
+struct GridPlan { int rows, nsplit; };
+constexpr long PLAN_TARGET_WORKGROUPS = 7000;
+
+GridPlan plan_grid(int n_prob, int a_rows, int b_rows) {
+    const int tiles_b = std::max(1, slam_div_up(b_rows, TILE_B));
+    if (const char *e = std::getenv("SLAM_MATCH_PLAN")) {             // "rows,nsplit": tuning runs only (tools/sweep_grid_plan.py)
+        int r = 0, ns = 0;
+        if (std::sscanf(e, "%d,%d", &r, &ns) == 2 && r >= 1 && r <= 4 && ns >= 1)
+            return {r, std::min(std::min(ns, MAX_SPLIT), tiles_b)};
+    }
+    const long tiles_a = (long)slam_div_up(a_rows, TILE_A) * (n_prob > 0 ? n_prob : 1);
+    long ns = (PLAN_TARGET_WORKGROUPS + tiles_a - 1) / tiles_a;
+    ns = std::min<long>(ns, std::min(tiles_b, 16));
+    return {ROWS, ns < 1 ? 1 : (int)ns};
 }
 
-void launch_allpairs(const MatchBatch &mb, int a_rows, int norm, hipStream_t st) {
-    if (small_grid(mb.n_prob, a_rows))
-        launch_allpairs_rows<ROWS_SMALL>(mb, a_rows, norm, st);
-    else
-        launch_allpairs_rows<ROWS>(mb, a_rows, norm, st);
-}
-
-// B splits for n_prob problems of a_rows x b_rows: 1 when the A tiles alone fill the chip, else enough splits for about
-// 1024 workgroups (each split scans at least one B tile)
-int pick_nsplit(int n_prob, int a_rows, int b_rows) {
-    const long tiles_a = (long)slam_div_up(a_rows, small_grid(n_prob, a_rows) ? ROWS_SMALL * BLOCK : TILE_A) * (n_prob > 0 ? n_prob : 1);
-    const int tiles_b = slam_div_up(b_rows, TILE_B);
-    if (tiles_a >= CHIP_WORKGROUPS) return 1;
-    long ns = 1024 / (tiles_a > 0 ? tiles_a : 1);
-    if (ns > tiles_b) ns = tiles_b;
-    if (ns > MAX_SPLIT) ns = MAX_SPLIT;
-    return ns < 1 ? 1 : (int)ns;
+void launch_allpairs(const MatchBatch &mb, int a_rows, int norm, int rows, hipStream_t st) {
+#ifdef SLAM_MATCH_ALL_ROW_VARIANTS
+    if (rows == 1) return launch_allpairs_rows<1>(mb, a_rows, norm, st);
+    if (rows == 3) return launch_allpairs_rows<3>(mb, a_rows, norm, st);
+    if (rows == 4) return launch_allpairs_rows<4>(mb, a_rows, norm, st);
+    if (rows == 2) return launch_allpairs_rows<2>(mb, a_rows, norm, st);
+#endif
+    (void)rows;
+    launch_allpairs_rows<ROWS>(mb, a_rows, norm, st);
 }
 
 // keys of scratch a match call needs: per direction and list, n_prob x nsplit x part_rows
@@ -524,8 +534,10 @@ int run_match(const char *who, MatchBatch mb, int q_rows, int t_rows, int norm, 
     const int n_prob = mb.n_prob;
     // one split count for both directions, so that they share the partial layout
     const int part_rows = q_rows > t_rows ? q_rows : t_rows;
-    int nsplit = knn ? pick_nsplit(n_prob, q_rows, t_rows) : pick_nsplit(n_prob, t_rows, q_rows);
-    if (mutual) nsplit = std::min(nsplit, pick_nsplit(n_prob, q_rows, t_rows));
+    // lanes own the query rows (kNN, and the second pass of the mutual rule) or the train rows (cross-check)
+    const GridPlan plan_q = plan_grid(n_prob, q_rows, t_rows), plan_t = plan_grid(n_prob, t_rows, q_rows);
+    int nsplit = knn ? plan_q.nsplit : plan_t.nsplit;
+    if (mutual) nsplit = std::min(nsplit, plan_q.nsplit);
     const size_t need = scratch_keys(n_prob, part_rows, nsplit, mode) * sizeof(unsigned);
     if (scratch_bytes < need || !scratch) {
         slam_set_error("%s: workspace %zu B < %zu B", who, scratch_bytes, need);
@@ -546,13 +558,13 @@ int run_match(const char *who, MatchBatch mb, int q_rows, int t_rows, int norm, 
     if (knn) {
         fwd.out1 = scratch;
         fwd.out2 = scratch + dir_keys;
-        launch_allpairs(fwd, q_rows, norm, st);
+        launch_allpairs(fwd, q_rows, norm, plan_q.rows, st);
     } else {
         rev.out1 = scratch;
-        launch_allpairs(rev, t_rows, norm, st);
+        launch_allpairs(rev, t_rows, norm, plan_t.rows, st);
         if (mutual) {
             fwd.out1 = scratch + dir_keys;
-            launch_allpairs(fwd, q_rows, norm, st);
+            launch_allpairs(fwd, q_rows, norm, plan_q.rows, st);
         }
     }
     SLAM_HIP_CHECK(hipGetLastError());
@@ -698,11 +710,12 @@ extern "C" int slam_match_hamming_noalloc(const uint8_t *d_query, int n_query, c
 }
 
 // Enough for ANY batch of up to n_prob problems (a caller sizes one workspace for its largest batch and reuses it for
-// smaller ones, which split B more often): n x nsplit(n) <= max(n, min(n x B tiles, 1024 / A tiles per problem)).
+// smaller ones, which split B more often): plans never launch more than PLAN_MAX_WORKGROUPS workgroups when they split,
+// so n x nsplit(n) <= max(n, min(n x B tiles, PLAN_MAX_WORKGROUPS / A tiles per problem)).
 extern "C" size_t slam_match_batched_workspace_bytes(int n_prob, int n_max, int mode) {
     if (n_prob <= 0 || n_max <= 0) return 256;
-    const long tiles_b = slam_div_up(n_max, TILE_B), tpp = slam_div_up(n_max, ROWS_SMALL * BLOCK);
-    const long split_bound = std::min<long>((long)n_prob * std::min<long>(tiles_b, MAX_SPLIT), 1024 / tpp > 0 ? 1024 / tpp : 1);
+    const long tiles_b = slam_div_up(n_max, TILE_B), tpp = slam_div_up(n_max, TILE_A);
+    const long split_bound = std::min<long>((long)n_prob * std::min<long>(tiles_b, MAX_SPLIT), PLAN_MAX_WORKGROUPS / tpp);
     const long units = std::max<long>(n_prob, split_bound);
     return scratch_keys(1, n_max, 1, mode) * (size_t)units * sizeof(unsigned) + 256;
 }

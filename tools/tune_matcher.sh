@@ -30,7 +30,7 @@ txt = open(sys.argv[2]).read()
 blocks = re.split(r"remark: [^\n]*Function Name: ", txt)
 for b in blocks[1:]:
     name = b.split("\n", 1)[0]
-    if "allpairs_top2_kernel" in name and "Lb1ELb1ELb0E" in name:
+    if "allpairs_top2_kernel" in name and "Lb1ELb0ELi" in name:
         g = lambda k: (re.search(k + r": (\d+)", b) or [None, "?"])[1]
         print(sys.argv[1] + sys.argv[3], "VGPRs", g("VGPRs"), "AGPRs", g("AGPRs"), "ScratchSize[bytes/lane]", g(r"ScratchSize \[bytes/lane\]"),
               "VGPR spills", g("VGPRs Spill"), "occupancy[waves/SIMD]", g(r"Occupancy \[waves/SIMD\]"), "LDS", g(r"LDS Size \[bytes/block\]"))
@@ -50,7 +50,7 @@ elif [ "$1" = run ]; then
     IFS=, read r b t <<< "$v"
     lib=$PWD/tune/lib_r${r}_b${b}_t${t}${SUFFIX}.so
     [ -f $lib ] || { echo "$v missing" >> $out/summary.txt; continue; }
-    SLAM_AMD_LIB=$lib timeout -k 10 120 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ingest --chunks 1 \
+    SLAM_AMD_LIB=$lib timeout -k 10 120 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ingest --no-dropin --chunks 1 \
         > $out/r${r}_b${b}_t${t}${SUFFIX}.json 2> $out/r${r}_b${b}_t${t}${SUFFIX}.err
     python - "$v" $out/r${r}_b${b}_t${t}${SUFFIX}.json "$SUFFIX" >> $out/summary.txt <<'PY'
 import json, sys
