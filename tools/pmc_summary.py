@@ -41,12 +41,21 @@ def main(src, prefix):
                     k = short_name(row["Kernel_Name"])
                     per[k][row["Counter_Name"]] += float(row["Counter_Value"])
                     disp[(k, os.path.basename(run))].add(row["Dispatch_Id"])
+    # average duration of every kernel in the single-lane trace that belongs to these PMC passes (bench.py compares its
+    # live figure with it and flags the traffic number as stale when the kernel has changed since)
+    trace_ms = {}
+    for f in glob.glob(os.path.join(src, "trace_chunks1", "**", "*_kernel_stats.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                trace_ms[short_name(row["Name"])] = round(float(row["AverageNs"]) / 1e6, 4)
     out = {}
     for k, c in per.items():
         if "at::native" in k or k.startswith("at::") or "elementwise" in k:
             continue
         n = max(len(v) for (kk, _), v in disp.items() if kk == k)
         e = {"dispatches": n}
+        if k in trace_ms:
+            e["trace_avg_ms"] = trace_ms[k]
         e.update({name: val for name, val in sorted(c.items())})
         if "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"] > 0 and "SQ_ACTIVE_INST_VALU" in c:
             # share of resident-wave time spent issuing VALU instructions
