@@ -76,7 +76,7 @@ int slam_match_hamming(const uint8_t *d_query, int n_query, const uint8_t *d_tra
 /* slam_match_hamming for callers that cannot allocate device memory and have no workspace to bring: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference (which
  * never touches a GPU); it exists only for those callers.  Same inputs, outputs and results as slam_match_hamming; the
- * per-split partial lists live in a static device array inside the library (4 MiB per GPU, held until the process
+ * per-split partial lists live in a static device array inside the library (4.5 MiB per GPU, held until the process
  * ends) instead of a caller workspace, so n_query and n_train must each be <= SLAM_MATCH_NOALLOC_MAX_ROWS (larger
  * sizes return SLAM_E_INVALID and launch nothing).  The call allocates and frees nothing (no hipMalloc / hipFree, no
  * allocating library routine).  The device that owns `stream` must be current.  All calls on one GPU share that

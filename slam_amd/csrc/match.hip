@@ -84,6 +84,7 @@ struct MatchBatch {
     unsigned *out1, *out2;    // nearest / second nearest B row of every A row: [problem][split][part_rows] keys
     int out_stride;           // keys per problem = nsplit * part_rows
     int part_rows;            // keys per split (>= A rows of any problem)
+    unsigned *col_out;        // COLMIN: nearest A row of every B row, per A tile: [problem][A tile][part_rows] keys
     int tiles_per_prob;       // A tiles per problem
     int nsplit;               // B splits (blockIdx.y)
     int n_prob;
@@ -142,11 +143,31 @@ __device__ __forceinline__ void top2_insert(unsigned &m1, unsigned &m2, unsigned
     m1 = min(m1, key);
 }
 
+// minimum over every row of 16 lanes, returned in the row's last lane (15, 31, 47, 63): DPP row shifts, the moves ride
+// on the v_min instructions, no LDS traffic
+__device__ __forceinline__ unsigned row16_min_to_last_lane(unsigned v) {
+#define SLAM_DPP_MIN(ctrl) v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, ctrl, 0xf, 0xf, false))
+    SLAM_DPP_MIN(0x111);      // row_shr:1
+    SLAM_DPP_MIN(0x112);      // row_shr:2
+    SLAM_DPP_MIN(0x114);      // row_shr:4
+    SLAM_DPP_MIN(0x118);      // row_shr:8
+#undef SLAM_DPP_MIN
+    return v;
+}
+
 // TOP2: keep the second best too (kNN mode); the cross-check rules need only the nearest row.
+// COLMIN (mutual cross-check): besides every A row's nearest B row, every B row's nearest A row among this workgroup's
+// A rows (first minimum: lowest A row on equal distance), so that one pass over the distance matrix yields both
+// directions.  Per B row that is two key builds, one minimum and four DPP minima per lane and one LDS store from
+// four lanes (~28 issue cycles against the 132 of the two distances), instead of a second all-pairs pass.
 // RW = A rows per lane (ROWS = 2 in the shipped library; 1, 3, 4 exist in tuning builds, see plan_grid).
-template <bool NORM2, bool TOP2, int RW>
+template <bool NORM2, bool TOP2, int RW, bool COLMIN = false>
 __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
     __shared__ uint4 tile[2][TILE_B * 4];
+    // COLMIN: per wavefront and B row of the tile in flight, the minima of the wavefront's four rows of 16 lanes (plain
+    // stores: LDS atomics from a few lanes per instruction turned out several times dearer than the distances)
+    constexpr int WAVES = BLOCK / 64;
+    __shared__ __align__(16) unsigned colmin[COLMIN ? WAVES : 1][COLMIN ? TILE_B : 1][COLMIN ? 4 : 1];
     constexpr int ROWS = RW;                 // shadows the file-scope default inside the kernel
     constexpr int TILE_A = ROWS * BLOCK;
 
@@ -211,6 +232,11 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
     unsigned gate[ROWS];          // distance a new row must beat: that of the worst entry kept
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) gate[r] = NONE >> SLAM_KEY_SHIFT;
+    // COLMIN: the low key bits of this lane's rows; rows beyond the image get all ones, so their keys are SLAM_KEY_NONE
+    unsigned rowbits[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) rowbits[r] = slot_row(r) < na ? (unsigned)slot_row(r) : NONE;
+    unsigned *col_out = COLMIN ? mb.col_out + ((size_t)p * mb.tiles_per_prob + tile_a) * mb.part_rows : nullptr;
 
     // prologue: first tile -> LDS.  A tile is TILE_B*4 uint4; each thread moves STAGE of them, coalesced.
     uint4 stage[STAGE];
@@ -315,6 +341,15 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
             // whole wave when no lane improves, which is the common case after the first few hundred rows.  JU rows
             // share one such test (inserting a row that does not improve is a no-op, so testing them together only
             // makes the rare path slightly less rare); the rows of a group are inserted in ascending order.
+            // COLMIN: this wavefront's nearest A row for B row j -> the tile's column slot in LDS.  Keys carry the A row
+            // in their low bits, so a minimum over keys is the first minimum (lowest A row on equal distance).
+            auto col_update = [&](int j, const unsigned (&d)[ROWS]) {
+                unsigned m = (d[0] << SLAM_KEY_SHIFT) | rowbits[0];
+#pragma unroll
+                for (int r = 1; r < NR; ++r) m = min(m, (d[r] << SLAM_KEY_SHIFT) | rowbits[r]);
+                m = row16_min_to_last_lane(m);
+                if ((tid & 15) == 15) colmin[tid >> 6][j][(tid >> 4) & 3] = m;
+            };
             constexpr int JU = SLAM_JUNROLL;
             int j = 0;
             for (; j + JU <= rows_here; j += JU) {
@@ -322,6 +357,10 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
                 bool improves = false;
 #pragma unroll
                 for (int u = 0; u < JU; ++u) improves |= dist_row(j + u, d[u]);
+                if (COLMIN) {
+#pragma unroll
+                    for (int u = 0; u < JU; ++u) col_update(j + u, d[u]);
+                }
                 if (__any(improves)) {
 #pragma unroll
                     for (int u = 0; u < JU; ++u) insert_row(j + u, d[u]);
@@ -329,7 +368,9 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
             }
             for (; j < rows_here; ++j) {
                 unsigned d[ROWS];
-                if (__any(dist_row(j, d))) insert_row(j, d);
+                const bool improves = dist_row(j, d);
+                if (COLMIN) col_update(j, d);
+                if (__any(improves)) insert_row(j, d);
             }
         };
 #if SLAM_ROW_VARIANTS
@@ -339,6 +380,22 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
 #endif
         if (more) store_tile(buf ^ 1);
         __syncthreads();
+        if (COLMIN) {
+            // the tile's column minima: 4 wavefronts x 4 lane rows per B row -> one key per B row of this A tile
+            if (tid < rows_here) {
+                unsigned m = NONE;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) {
+                    const int wrow0 = row0 + w * (ROWS * 64);
+                    if (wrow0 < na) {                                   // wavefronts without rows wrote nothing
+                        const uint4 q = *(const uint4 *)colmin[w][tid];
+                        m = min(min(m, min(q.x, q.y)), min(q.z, q.w));
+                    }
+                }
+                col_out[jbase + tid] = m;
+            }
+            __syncthreads();                                            // before the next tile's scan overwrites the slots
+        }
     }
 
 #pragma unroll
@@ -363,6 +420,9 @@ struct ResolveArgs {
     int out_stride, out_rows;        // out_rows keys of every problem are written (rows beyond nq: SLAM_KEY_NONE)
     double ratio;                    // KNN2: > 0 applies the ratio test to key1
     int slots_in_lds;                // CROSSCHECK: query slots fit the LDS array (else global atomics on a pre-set out1)
+    // MUTUAL, fused form: the query direction comes from the same pass as per-A-tile column minima
+    const unsigned *col;             // [problem][A tile][part_rows], or NULL: second direction in part1 behind the first
+    int col_tiles, col_tile_rows;    // A tiles per problem slot, train rows per A tile
 };
 
 constexpr int RESOLVE_BLOCK = 256;
@@ -414,11 +474,15 @@ __global__ __launch_bounds__(RESOLVE_BLOCK) void resolve_kernel(ResolveArgs ra) 
         // direction Q (problem n_prob + p): lanes owned query rows, part = nearest train of every query row.
         // Query i keeps its nearest train j (first minimum) iff j's nearest query (first minimum) is i.
         const unsigned *part_t = ra.part1 + (size_t)p * ra.part_stride;
-        const unsigned *part_q = ra.part1 + (size_t)(ra.n_prob + p) * ra.part_stride;
+        // nearest train of every query row: column minima of the train tiles that hold rows (fused pass), or the
+        // second all-pairs pass' lists
+        const unsigned *part_q = ra.col ? ra.col + (size_t)p * ra.col_tiles * ra.part_rows
+                                        : ra.part1 + (size_t)(ra.n_prob + p) * ra.part_stride;
+        const int q_lists = ra.col ? (nt + ra.col_tile_rows - 1) / ra.col_tile_rows : ra.nsplit;
         for (int i = threadIdx.x; i < ra.out_rows; i += RESOLVE_BLOCK) {
             unsigned key = NONE;
             if (i < nq) {
-                const unsigned mq = merged_top1(part_q, ra.nsplit, ra.part_rows, i);
+                const unsigned mq = merged_top1(part_q, q_lists, ra.part_rows, i);
                 if (mq != NONE) {
                     const unsigned mt = merged_top1(part_t, ra.nsplit, ra.part_rows, (int)(mq & idx_mask));
                     if (mt != NONE && (mt & idx_mask) == (unsigned)i) key = mq;
@@ -467,15 +531,19 @@ void launch_allpairs_rows(MatchBatch mb, int a_rows, int norm, hipStream_t st) {
     mb.tiles_per_prob = slam_div_up(a_rows, RW * BLOCK);
     const unsigned total = (unsigned)mb.tiles_per_prob * (unsigned)mb.n_prob;
     dim3 grid((total + 7u) / 8u * 8u, mb.nsplit);
-    const bool top2 = mb.out2 != nullptr;
+    const bool top2 = mb.out2 != nullptr, colmin = mb.col_out != nullptr;
     if (norm == SLAM_NORM_HAMMING2) {
         if (top2)
             hipLaunchKernelGGL((allpairs_top2_kernel<true, true, RW>), grid, dim3(BLOCK), 0, st, mb);
+        else if (colmin)
+            hipLaunchKernelGGL((allpairs_top2_kernel<true, false, RW, true>), grid, dim3(BLOCK), 0, st, mb);
         else
             hipLaunchKernelGGL((allpairs_top2_kernel<true, false, RW>), grid, dim3(BLOCK), 0, st, mb);
     } else {
         if (top2)
             hipLaunchKernelGGL((allpairs_top2_kernel<false, true, RW>), grid, dim3(BLOCK), 0, st, mb);
+        else if (colmin)
+            hipLaunchKernelGGL((allpairs_top2_kernel<false, false, RW, true>), grid, dim3(BLOCK), 0, st, mb);
         else
             hipLaunchKernelGGL((allpairs_top2_kernel<false, false, RW>), grid, dim3(BLOCK), 0, st, mb);
     }
@@ -515,10 +583,16 @@ void launch_allpairs(const MatchBatch &mb, int a_rows, int norm, int rows, hipSt
     launch_allpairs_rows<ROWS>(mb, a_rows, norm, st);
 }
 
-// keys of scratch a match call needs: per direction and list, n_prob x nsplit x part_rows
-size_t scratch_keys(int n_prob, int part_rows, int nsplit, int mode) {
-    const size_t lists = mode == SLAM_MATCH_CROSSCHECK ? 1 : 2;       // MUTUAL: two directions; KNN2: two lists
-    return lists * (size_t)n_prob * (size_t)nsplit * (size_t)part_rows;
+// The mutual rule runs fused (column minima out of the train-side pass) while a problem slot has at most this many
+// A tiles (8192 train rows at 2 rows per lane); beyond that, two all-pairs passes.
+constexpr int FUSED_MUTUAL_MAX_TILES = 16;
+
+// keys of scratch a match call needs: n_prob x nsplit x part_rows per direction / list, or for the fused mutual rule
+// n_prob x (nsplit + A tiles per problem) x part_rows
+size_t scratch_keys(int n_prob, int part_rows, int nsplit, int mode, int col_tiles) {
+    size_t lists = mode == SLAM_MATCH_CROSSCHECK ? nsplit : 2 * (size_t)nsplit;     // MUTUAL: two directions; KNN2: two lists
+    if (mode == SLAM_MATCH_CROSSCHECK_MUTUAL && col_tiles > 0) lists = (size_t)nsplit + col_tiles;
+    return lists * (size_t)n_prob * (size_t)part_rows;
 }
 
 template <int MODE>
@@ -538,7 +612,11 @@ int run_match(const char *who, MatchBatch mb, int q_rows, int t_rows, int norm, 
     const GridPlan plan_q = plan_grid(n_prob, q_rows, t_rows), plan_t = plan_grid(n_prob, t_rows, q_rows);
     int nsplit = knn ? plan_q.nsplit : plan_t.nsplit;
     if (mutual) nsplit = std::min(nsplit, plan_q.nsplit);
-    const size_t need = scratch_keys(n_prob, part_rows, nsplit, mode) * sizeof(unsigned);
+    // mutual rule: one pass with column minima when the train side has few A tiles, else two passes
+    const int t_tiles = slam_div_up(t_rows, plan_t.rows * BLOCK);
+    const bool fused = mutual && t_tiles <= FUSED_MUTUAL_MAX_TILES;
+    if (fused) nsplit = plan_t.nsplit;
+    const size_t need = scratch_keys(n_prob, part_rows, nsplit, mode, fused ? t_tiles : 0) * sizeof(unsigned);
     if (scratch_bytes < need || !scratch) {
         slam_set_error("%s: workspace %zu B < %zu B", who, scratch_bytes, need);
         return SLAM_E_WORKSPACE;
@@ -554,6 +632,7 @@ int run_match(const char *who, MatchBatch mb, int q_rows, int t_rows, int norm, 
         m->part_rows = part_rows;
         m->out_stride = nsplit * part_rows;
         m->out2 = nullptr;
+        m->col_out = nullptr;
     }
     if (knn) {
         fwd.out1 = scratch;
@@ -561,8 +640,9 @@ int run_match(const char *who, MatchBatch mb, int q_rows, int t_rows, int norm, 
         launch_allpairs(fwd, q_rows, norm, plan_q.rows, st);
     } else {
         rev.out1 = scratch;
+        if (fused) rev.col_out = scratch + dir_keys;
         launch_allpairs(rev, t_rows, norm, plan_t.rows, st);
-        if (mutual) {
+        if (mutual && !fused) {
             fwd.out1 = scratch + dir_keys;
             launch_allpairs(fwd, q_rows, norm, plan_q.rows, st);
         }
@@ -587,6 +667,9 @@ int run_match(const char *who, MatchBatch mb, int q_rows, int t_rows, int norm, 
     ra.out_rows = out_rows;
     ra.ratio = ratio;
     ra.slots_in_lds = q_rows <= LDS_SLOTS;
+    ra.col = fused ? scratch + dir_keys : nullptr;
+    ra.col_tiles = t_tiles;
+    ra.col_tile_rows = plan_t.rows * BLOCK;
     if (mode == SLAM_MATCH_CROSSCHECK) {
         if (!ra.slots_in_lds)
             SLAM_HIP_CHECK(hipMemsetAsync(d_key1, 0xFF, sizeof(uint32_t) * ((size_t)(n_prob - 1) * out_stride + out_rows), st));
@@ -643,7 +726,7 @@ int match_single_check_args(const char *who, const uint8_t *d_query, int n_query
 
 extern "C" size_t slam_match_workspace_bytes(int n_query, int n_train) {
     const size_t n = (size_t)(n_query > n_train ? n_query : n_train);
-    return 2 * MAX_SPLIT * n * sizeof(unsigned) + 256;        // two lists / directions x at most 64 splits
+    return (2 * MAX_SPLIT + FUSED_MUTUAL_MAX_TILES) * n * sizeof(unsigned) + 256;   // two lists / directions x at most 64 splits
 }
 
 extern "C" int slam_match_hamming(const uint8_t *d_query, int n_query, const uint8_t *d_train, int n_train, int norm,
@@ -659,11 +742,11 @@ extern "C" int slam_match_hamming(const uint8_t *d_query, int n_query, const uin
 // ---------------------------------------------------------------------------------------------------------------
 // The same matcher for callers that cannot allocate (code under HIP graph capture, serving loops, harnesses that
 // forbid hipMalloc).  The per-split partial lists -- the scratch buffer slam_match_hamming takes from its caller's
-// workspace -- live in a file-scope device array instead: 2 lists x 64 splits x SLAM_MATCH_NOALLOC_MAX_ROWS keys
-// = 4 MiB, held by every GPU the library runs on until the process ends.  In host code the array's NAME is only a
+// workspace -- live in a file-scope device array instead: (2 lists x 64 splits + 16 column tiles) x
+// SLAM_MATCH_NOALLOC_MAX_ROWS keys = 4.5 MiB, held by every GPU the library runs on until the process ends.  In host code the array's NAME is only a
 // stand-in for the symbol; its address on a device comes from hipGetSymbolAddress, asked once per device with that
 // device current, and only that pointer is handed to kernels.
-constexpr size_t NOALLOC_WORDS = 2 * (size_t)MAX_SPLIT * SLAM_MATCH_NOALLOC_MAX_ROWS;
+constexpr size_t NOALLOC_WORDS = (2 * (size_t)MAX_SPLIT + FUSED_MUTUAL_MAX_TILES) * SLAM_MATCH_NOALLOC_MAX_ROWS;
 static __device__ __align__(256) unsigned scratch[NOALLOC_WORDS];
 
 namespace {
@@ -717,7 +800,10 @@ extern "C" size_t slam_match_batched_workspace_bytes(int n_prob, int n_max, int 
     const long tiles_b = slam_div_up(n_max, TILE_B), tpp = slam_div_up(n_max, TILE_A);
     const long split_bound = std::min<long>((long)n_prob * std::min<long>(tiles_b, MAX_SPLIT), PLAN_MAX_WORKGROUPS / tpp);
     const long units = std::max<long>(n_prob, split_bound);
-    return scratch_keys(1, n_max, 1, mode) * (size_t)units * sizeof(unsigned) + 256;
+    size_t keys = scratch_keys(1, n_max, 1, mode, 0) * (size_t)units;
+    if (mode == SLAM_MATCH_CROSSCHECK_MUTUAL)       // fused form: units split lists + the A tiles' column minima per problem
+        keys = std::max(keys, ((size_t)units + (size_t)n_prob * std::min<long>(tpp, FUSED_MUTUAL_MAX_TILES)) * (size_t)n_max);
+    return keys * sizeof(unsigned) + 256;
 }
 
 extern "C" int slam_match_hamming_batched(const uint8_t *d_desc, const int32_t *d_count, int n_max,
