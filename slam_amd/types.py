@@ -5,7 +5,11 @@
   They are classes with __slots__, NOT tuples: `np.array(matches)` (utills.py:110) must stay a 1-D object array.
 * `Feature` (DataBaseDirectory/Feature.py:3-39), `Frame` (Frame.py:5-58), `Track` (Trck.py:5-105),
   `DataBase` (DataBase.py:37-328): same constructors and accessors, re-implemented; they hold only Python/numpy
-  values, so a DataBase pickles exactly like the reference's (DataBase.py:15-34).
+  values, so a DataBase can be saved and loaded with pickle the way the reference does (`save` / `load`,
+  DataBase.py:15-34).  The FILES are not interchangeable with the reference's db_*.pickle files: a pickle names the
+  defining module and attributes (`DataBaseDirectory.DataBase.DataBase`, `_DataBase__tracks` there;
+  `slam_amd.types.DataBase`, `_tracks` here), so each side loads only what it saved.  `load` unpickles: use it on
+  files you wrote yourself, never on untrusted ones.
 """
 from __future__ import annotations
 

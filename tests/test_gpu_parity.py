@@ -511,6 +511,57 @@ def test_refit_against_oracle():
     assert err <= REL_TOL, err                                        # north_star: 1e-5 relative
 
 
+def _reproj_cost(T, X, l):
+    return float(np.sum((orc.project(X, K @ T) - l) ** 2))
+
+
+@pytest.mark.parametrize("case", ["near_planar", "low_parallax", "coincident_points"])
+def test_refit_on_ill_conditioned_supporter_sets(case):
+    """Refit parity is pinned to the oracle's minimiser only (cv2's SOLVEPNP_ITERATIVE is absent offline, DESIGN.md
+    section 2), and the two solvers start differently: the kernel from the winning RANSAC pose, the oracle / cv2 from a DLT
+    initialisation.  So on ill-conditioned sets the basin is NOT assumed shared: the kernel's pose must be a minimum
+    at least as good as the oracle's (cost no higher beyond rounding), equal to it within 1e-5 where the costs agree,
+    with status 1; supporters that are all one point leave the normal equations singular: the pose then stays finite
+    (the RANSAC winner, possibly moved along the null space without raising the cost), status 1."""
+    rng = np.random.default_rng({"near_planar": 1, "low_parallax": 2, "coincident_points": 3}[case])
+    T0 = np.hstack([orc.rodrigues_vec_to_mat(np.array([0.01, -0.03, 0.005])), np.array([[0.05], [-0.02], [-0.8]])])
+    n = 400
+    if case == "near_planar":
+        X = np.stack([rng.uniform(-8, 8, n), rng.uniform(-2, 2, n), 20.0 + rng.normal(0, 1e-3, n)], 1)   # a wall, 1 mm rough
+    elif case == "low_parallax":
+        X = np.stack([rng.uniform(-300, 300, n), rng.uniform(-60, 40, n), rng.uniform(900, 1000, n)], 1)  # everything ~1 km away
+    else:
+        X = np.tile(np.array([[1.0, -0.5, 12.0]]), (n, 1))
+    l = (orc.project(X, K @ T0) + rng.normal(0, 0.3, (n, 2))).astype(np.float32)
+    r = (orc.project(X, K @ orc.compose(T0, M2)) + rng.normal(0, 0.3, (n, 2))).astype(np.float32)
+    stride = 448
+    Xs = np.zeros((1, stride, 3)); Xs[0, :n] = X
+    xy1 = np.zeros((1, stride, 4), np.float32); xy1[0, :n] = np.hstack([l, r])
+    mask = np.ones((1, n), bool)
+    start = T0.copy()
+    start[:, 3] += [0.02, -0.01, 0.05]                         # a RANSAC-quality start, a few pixels off
+    pose, status = ops.refit_pnp(K, dev(Xs), dev(xy1), dev(np.array([n], np.int32)), dev(ops.bool_to_mask_words(mask, stride)),
+                                 dev(start[None]))
+    pose, status = pose.cpu().numpy()[0], status.cpu().numpy()
+    assert status[0] == 1 and np.isfinite(pose).all()
+    c_start, c_got = _reproj_cost(start, X, l.astype(np.float64)), _reproj_cost(pose, X, l.astype(np.float64))
+    assert c_got <= c_start * (1 + 1e-12)                      # LM never accepts a worse pose
+    if case == "coincident_points":
+        R = pose[:, :3]
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-9        # still a rigid pose
+        return
+    with np.errstate(all="ignore"):
+        want = orc.pnp(X, l.astype(np.float64), K, orc.SOLVEPNP_ITERATIVE)
+    assert want is not None
+    c_want = _reproj_cost(want, X, l.astype(np.float64))
+    assert c_got <= c_want * (1 + 1e-9), (c_got, c_want)       # a minimum at least as good as the oracle's
+    if abs(c_got - c_want) <= 1e-9 * c_want:
+        # same cost: on a flat valley (low parallax) the poses may still sit apart along it, so the pose check is
+        # made only where the problem is well posed enough for the oracle itself to be converged
+        err = np.linalg.norm(pose - want) / np.linalg.norm(want)
+        assert err <= (REL_TOL if case == "near_planar" else 1e-3), err
+
+
 def test_full_pipeline_against_oracle_sequence():
     from slam_amd.pipeline import ShardTracker, consecutive_pairs
     seq, desc, xy, count = _small_sequence(n_frames=6, n_features=320, seed=9)
