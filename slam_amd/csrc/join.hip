@@ -29,7 +29,7 @@ __global__ __launch_bounds__(JB) void rect_join_kernel(const float2 *xy, const i
     __shared__ int cnt_aux[2][JB / 64];
     const int p = blockIdx.x;
     const int f0 = pf0[p], f1 = pf1[p];
-    const int nl0 = count[2 * f0];
+    const int nl0 = min(max(count[2 * f0], 0), n_max);      // caller's count, clamped to the image slot
     const float2 *xl0 = xy + (size_t)(2 * f0) * n_max, *xr0 = xy + (size_t)(2 * f0 + 1) * n_max;
     const float2 *xl1 = xy + (size_t)(2 * f1) * n_max, *xr1 = xy + (size_t)(2 * f1 + 1) * n_max;
     const unsigned *s0 = stereo + (size_t)f0 * n_max, *s1 = stereo + (size_t)f1 * n_max;

@@ -190,8 +190,10 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
         const int ia = mb.prob_a[p], ib = mb.prob_b[p];
         A = mb.desc + (size_t)ia * mb.n_max * 4;
         B = mb.desc + (size_t)ib * mb.n_max * 4;
-        na = mb.count[ia];
-        nb = mb.count[ib];
+        // counts come from the caller's device array: clamp them to the image slot, so that a bad count can make a
+        // result meaningless but never an access out of bounds
+        na = min(max(mb.count[ia], 0), mb.n_max);
+        nb = min(max(mb.count[ib], 0), mb.n_max);
     } else {
         A = mb.a_ptr;
         B = mb.b_ptr;
@@ -440,8 +442,8 @@ __global__ __launch_bounds__(RESOLVE_BLOCK) void resolve_kernel(ResolveArgs ra) 
     const int p = blockIdx.x;
     int nq, nt;
     if (ra.count) {
-        nq = ra.count[ra.prob_q[p]];
-        nt = ra.count[ra.prob_t[p]];
+        nq = min(max(ra.count[ra.prob_q[p]], 0), ra.part_rows);        // clamped as in the all-pairs kernel
+        nt = min(max(ra.count[ra.prob_t[p]], 0), ra.part_rows);
     } else {
         nq = ra.nq;
         nt = ra.nt;

@@ -14,16 +14,27 @@ for _p in (_ROOT, os.path.join(_ROOT, "oracle")):
 
 _SEQ = None
 _KW = None
+_MATCHER = None
 
 
-def _init(cfg_kwargs, ransac_kw):
-    global _SEQ, _KW
+def _init(cfg_kwargs, ransac_kw, matcher=None):
+    global _SEQ, _KW, _MATCHER
     import c_oracle
     import slam_oracle as orc
     from slam_amd.synth import SynthConfig, SynthSequence
     orc.bf_match = lambda a, b, norm=7: c_oracle.match_crosscheck_w64(c_oracle.pad64(a), c_oracle.pad64(b), norm)
     _SEQ = SynthSequence(SynthConfig(**cfg_kwargs))
     _KW = dict(ransac_kw)
+    # what match() does (utils/utills.py:105-119): default cross-check (legacy rule), or the mutual rule / kNN + ratio
+    if matcher == "mutual":
+        _MATCHER = lambda a, b, norm=7: c_oracle.match_crosscheck(a, b, norm, mutual=True)
+    elif matcher == "knn_ratio":
+        def _knn(a, b, norm=7):
+            idx, dist = c_oracle.knn2(a, b, norm)
+            keep = dist[:, 0].astype(np.float64) < orc.RATIO * dist[:, 1].astype(np.float64)
+            q = np.nonzero(keep)[0].astype(np.int32)
+            return q, idx[q, 0], dist[q, 0]
+        _MATCHER = _knn
 
 
 def _frame(i):
@@ -40,7 +51,7 @@ def _pair(job):
     np.random.seed(int(seed))
     st = {}
     with np.errstate(all="ignore"):
-        w = orc.track_pair(_frame(f0), _frame(f1), stats=st, **_KW)
+        w = orc.track_pair(_frame(f0), _frame(f1), stats=st, matcher=_MATCHER, **_KW)
     np.random.seed(int(seed))
     n, noisy = len(w["kp"]), 0
     for _ in range(st["draws"] + 64):                # + slack: the other side may have consumed a few more draws
@@ -55,11 +66,12 @@ def cpu_share():
     return max(1, min(n, 16))
 
 
-def run(cfg_kwargs, jobs, ransac_kw=None, workers=None):
-    """jobs: iterable of (key, frame0, frame1, seed).  Returns {key: result tuple without the key}."""
+def run(cfg_kwargs, jobs, ransac_kw=None, workers=None, matcher=None):
+    """jobs: iterable of (key, frame0, frame1, seed).  Returns {key: result tuple without the key}.
+    matcher: None (cross-check, legacy rule), "mutual" or "knn_ratio"."""
     workers = workers or cpu_share()
     out = {}
-    with mp.get_context("spawn").Pool(workers, initializer=_init, initargs=(cfg_kwargs, ransac_kw or {})) as pool:
+    with mp.get_context("spawn").Pool(workers, initializer=_init, initargs=(cfg_kwargs, ransac_kw or {}, matcher)) as pool:
         for r in pool.imap_unordered(_pair, list(jobs), chunksize=4):
             out[r[0]] = r[1:]
     return out

@@ -236,6 +236,32 @@ def test_degenerate_frames_empty_and_tiny():
     assert np.linalg.norm(res.pose[0] - want["T"]) / np.linalg.norm(want["T"]) <= REL_TOL
 
 
+def test_image_counts_outside_the_slot_are_clamped_not_trusted():
+    """The per-image row counts are a caller-provided device array the host cannot check without a sync: a count
+    above n_max or below zero is clamped to the image slot inside the kernels (same results as the clamped count),
+    never an out-of-bounds access."""
+    cfg = SynthConfig(n_frames=40, n_features=300, seed=4, spawn_per_frame=40, ragged=13)
+    desc, xy, count = SynthSequence(cfg).frames(0, 4)
+    F, n_max = 4, cfg.n_max
+    desc[:, :, :, :61][np.arange(n_max)[None, None, :] >= count[:, :, None]] = 0           # rows past the count: zeros
+    bad = count.copy()
+    bad[1, 0] = n_max + 100000                  # beyond the slot -> n_max
+    bad[2, 1] = -7                              # negative -> 0
+    good = bad.copy()
+    good[1, 0], good[2, 1] = n_max, 0
+    f0, f1 = consecutive_pairs(F)
+    seeds = 77 + np.arange(F - 1)
+    run = lambda c: ShardTracker(F, F - 1, n_max).run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)),
+                                                      dev(c.reshape(2 * F)), f0, f1, seeds)
+    a, b = run(bad), run(good)
+    assert np.array_equal(a.stats, b.stats) and np.array_equal(a.mask, b.mask)
+    assert np.array_equal(a.pose, b.pose, equal_nan=True)
+    assert np.array_equal(a.tracked_kp.cpu().numpy(), b.tracked_kp.cpu().numpy())
+    # frame 2 has no right-image rows: both pairs that touch it have an empty tracked set; pair (0, 1) is unaffected
+    assert (b.stats[1, 5] & _lib.SLAM_PAIR_EMPTY) and (b.stats[2, 5] & _lib.SLAM_PAIR_EMPTY)
+    assert (b.stats[0, 5] & _lib.SLAM_PAIR_OK) and b.stats[0, 0] > 50
+
+
 def test_results_do_not_depend_on_chunk_plan():
     """pipeline_chunks / pipeline_taper_permille only schedule the work: every plan gives the single-lane result."""
     F = 60

@@ -83,3 +83,36 @@ def test_bench_workload_agrees_with_the_oracle_end_to_end():
     assert abs(a_gpu - a_orc) <= ATE_TOL * a_orc, (a_gpu, a_orc)
     print(f"end to end: pairs {len(picks)}, masks equal {n_mask_equal}, clean pairs {n_clean}, worst clean pose "
           f"deviation {worst_clean_pose:.2e}, ATE gpu {a_gpu:.4f} m vs oracle {a_orc:.4f} m")
+
+
+@pytest.mark.parametrize("how", ["mutual", "knn_ratio"])
+def test_bench_workload_tracked_sets_under_the_other_match_methods(how):
+    """The same workload with match() switched to the mutual cross-check rule / to REGULAR_KNN + ratio 0.6
+    (utils/utills.py:105-119), every 16th pair against the oracle run with the same matcher: tracked sets bit-exact
+    (that is where the matcher's output ends up), masks and loop counters on the pairs without a rounding-noise draw."""
+    from slam_amd.config import MUTUAL, REGULAR_KNN, HotPathConfig
+    cfg_kw = dict(n_frames=3450, n_features=2000, seed=1234)
+    cfg = SynthConfig(**cfg_kw)
+    F = 1200                                           # the first 1200 frames are enough for 75 sampled pairs
+    desc, xy, count = SynthSequence(cfg).frames(0, F)
+    n_max = cfg.n_max
+    f0, f1 = consecutive_pairs(F)
+    seeds = 1000 + np.arange(F - 1)
+    hp = HotPathConfig(crosscheck_rule=MUTUAL) if how == "mutual" else HotPathConfig(match_method=REGULAR_KNN)
+    res = ShardTracker(F, F - 1, n_max, hp, n_chunks=2).run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)),
+                                                            dev(count.reshape(2 * F)), f0, f1, seeds)
+    kp = res.tracked_kp.cpu().numpy()
+    picks = list(range(0, F - 1, 16))
+    want = _oracle_pool.run(cfg_kw, [(p, p, p + 1, seeds[p]) for p in picks], matcher=how)
+    clean = 0
+    for p in picks:
+        wkp, wmask, wit, wdraws, wbest, wT, noisy = want[p]
+        n = len(wkp)
+        assert res.stats[p, 0] == n and np.array_equal(kp[p, :n], wkp), f"tracked set of pair {p} differs ({how})"
+        if noisy:
+            continue
+        clean += 1
+        assert np.array_equal(np.packbits(res.mask[p, :n]), wmask), p
+        assert (res.stats[p, 2], res.stats[p, 4]) == (wit, wbest), p
+        assert np.linalg.norm(res.pose[p] - wT) / np.linalg.norm(wT) <= REL_TOL, p
+    assert clean >= len(picks) // 2
