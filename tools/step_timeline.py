@@ -12,7 +12,8 @@ def main():
     d = sys.argv[1]
     step = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     rows = list(csv.DictReader(open(glob.glob(d + "/*/*kernel_trace.csv")[0])))
-    cop = list(csv.DictReader(open(glob.glob(d + "/*/*memory_copy_trace.csv")[0])))
+    cf = glob.glob(d + "/*/*memory_copy_trace.csv")          # optional: a --kernel-trace only run has none
+    cop = list(csv.DictReader(open(cf[0]))) if cf else []
     al = sorted(int(r["Start_Timestamp"]) for r in rows if "allpairs" in r["Kernel_Name"])
     lanes = 2
     t_a, t_b = al[step * lanes], al[(step + 1) * lanes]
