@@ -46,16 +46,22 @@ def all_gather_rows(local: torch.Tensor, n_total: int, world: int, rank: int) ->
 
 
 def gather_shard_results(pose_local: np.ndarray, stats_local: np.ndarray, n_pairs_total: int, device=None):
-    """pose_local float64[p, 3, 4], stats_local int32[p, 8] of this rank's pair block -> the full arrays on every rank."""
+    """pose_local float64[p, 3, 4], stats_local int32[p, 8] of this rank's pair block -> the full arrays on every rank.
+    One collective: a pair's pose (96 bytes) and counters (32 bytes) travel as one 128-byte row."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if not dist.is_initialized():
         return pose_local, stats_local
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
                                              if dist.get_backend() == "nccl" else torch.device("cpu"))
-    pose = all_gather_rows(torch.from_numpy(np.ascontiguousarray(pose_local)).reshape(-1, 12).to(dev), n_pairs_total, world, rank)
-    stats = all_gather_rows(torch.from_numpy(np.ascontiguousarray(stats_local)).to(dev), n_pairs_total, world, rank)
-    return pose.cpu().numpy().reshape(-1, 3, 4), stats.cpu().numpy()
+    p = len(pose_local)
+    row = np.empty((p, 128), np.uint8)
+    row[:, :96] = np.ascontiguousarray(pose_local, dtype=np.float64).reshape(p, 12).view(np.uint8)
+    row[:, 96:] = np.ascontiguousarray(stats_local, dtype=np.int32).reshape(p, 8).view(np.uint8)
+    full = all_gather_rows(torch.from_numpy(row).to(dev), n_pairs_total, world, rank).cpu().numpy()
+    pose = np.ascontiguousarray(full[:, :96]).view(np.float64).reshape(-1, 3, 4)
+    stats = np.ascontiguousarray(full[:, 96:]).view(np.int32).reshape(-1, 8)
+    return pose, stats
 
 
 def run_sharded(n_frames: int, run_shard, first_pose=None):

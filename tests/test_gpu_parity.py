@@ -406,8 +406,11 @@ def test_scoring_many_hypotheses_per_segment_lane_per_hypothesis_kernel(rig, xy_
         l1 = (orc.project(X, K @ T0) + rng.normal(0, 2.5, (n, 2))).astype(np.float32)
         r1 = (orc.project(X, K @ orc.compose(T0, M2)) + rng.normal(0, 2.5, (n, 2))).astype(np.float32)
         for h in range(H):
-            Ts[s, h] = np.hstack([orc.rodrigues_vec_to_mat(np.array([0.004, -0.02, 0.003]) + rng.normal(0, 0.002, 3)),
-                                  (T0[:, 3] + rng.normal(0, 0.02, 3))[:, None]])
+            # a third of the hypotheses close to the truth (points near the 4 px radius), a third moderately off (some
+            # blocks of points certainly outside, some not), a third garbage (what an outlier in the sample produces)
+            sr, st_ = ((0.002, 0.02), (0.02, 0.3), (0.8, 5.0))[h % 3]
+            Ts[s, h] = np.hstack([orc.rodrigues_vec_to_mat(np.array([0.004, -0.02, 0.003]) + rng.normal(0, sr, 3)),
+                                  (T0[:, 3] + rng.normal(0, st_, 3))[:, None]])
         Ts[s, 1, 0, 1], Ts[s, 2, 1, 3], Ts[s, 3, 2, 0], Ts[s, 4, 0, 3], Ts[s, 5, 1, 0] = np.nan, np.inf, -np.inf, np.nan, -0.0
         Ts[s, 6] = np.nan                                              # what a degenerate sample produces
         Ts[s, 299, 2, 3] = np.inf
@@ -425,6 +428,7 @@ def test_scoring_many_hypotheses_per_segment_lane_per_hypothesis_kernel(rig, xy_
     assert np.array_equal(cnt.cpu().numpy(), want)
     assert np.array_equal(cnt_w.cpu().numpy(), want)
     assert want[-1].max() > 100 and (want[:, 6] == 0).all()
+    assert (want[-1, 2::3] == 0).mean() > 0.9 and (want[-1, 1::3] > 0).any()      # garbage / partly-off hypotheses are there
 
 
 def test_device_sample_stream_equals_numpy():
