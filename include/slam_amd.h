@@ -53,6 +53,7 @@ extern "C" {
 #define SLAM_E_WORKSPACE (-2)   /* workspace too small */
 #define SLAM_E_HIP (-3)         /* a HIP runtime call failed */
 #define SLAM_E_EMPTY (-4)       /* empty tracked set: the reference raises ValueError (utills.py:502) */
+#define SLAM_E_DUPLICATE (-5)   /* slam_chain_tracks: a key-point appears twice inside one pair */
 
 const char *slam_version(void);
 const char *slam_last_error_string(void);
@@ -203,6 +204,27 @@ int slam_refit_pnp(const double *h_K, const double *d_X, const void *d_xy1, int 
  * reference, which is harmless for [I|0]).  h_rel, h_global: [n][12] row-major 3x4.
  */
 int slam_compose_global(const double *h_rel, int n, double *h_global);
+
+/* ---------------------------------------------------------------------------------------------
+ * Track chaining (host).  Replaces DataBase.create_db / find_tracks_between_consecutive_frame
+ * (DataBaseDirectory/DataBase.py:56-153) on the hot path's index arrays: for every supporter of pair (i, i+1), in
+ * order, the frame-i LEFT key-point is looked up among the frame-i key-points the previous pair's supporters ended
+ * on; a hit extends that track, a miss opens track number n_tracks.  Numbering (encounter order) and the order of the
+ * track ids inside every frame are the reference's.
+ *   h_kp [M][4]              supporters as key-point indices (L_i, R_i, L_{i+1}, R_{i+1}), pair after pair
+ *   h_pair_ptr [n_pairs+1]   supporters of pair i are rows h_pair_ptr[i] .. h_pair_ptr[i+1]; M = h_pair_ptr[n_pairs]
+ *   n_kp                     left key-point indices are < n_kp
+ *   h_xy                     optional float32 [n_pairs+1][2][n_max][2] key-point coordinates (left, right) per frame
+ * Outputs, sized by the caller for the worst case (every supporter opens a track):
+ *   h_track_ptr [M+1], h_obs_frame [2M], h_obs_kp [2M][2], h_obs_xy [2M][4] (x_left, x_right, y_left, y_right; only
+ *   with h_xy), h_frame_ptr [n_pairs+2], h_frame_tracks [2M]; *h_n_tracks, *h_n_obs say how much of them is used:
+ *   observations of track t are rows h_track_ptr[t] .. h_track_ptr[t+1], ascending frame.
+ * SLAM_E_DUPLICATE when a left key-point of either frame appears twice inside a pair (the reference's dictionaries
+ * would overwrite; the hot path never produces that: the join emits ascending L_i and cross-check is injective).
+ */
+int slam_chain_tracks(const int32_t *h_kp, const int64_t *h_pair_ptr, int32_t n_pairs, int32_t n_kp, const float *h_xy,
+                      int32_t n_max, int64_t *h_track_ptr, int32_t *h_obs_frame, int32_t *h_obs_kp, double *h_obs_xy,
+                      int64_t *h_frame_ptr, int64_t *h_frame_tracks, int64_t *h_n_tracks, int64_t *h_n_obs);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole shard.  Replaces the body of find_features_in_consecutive_frames_whole_movie

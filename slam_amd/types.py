@@ -355,9 +355,15 @@ class LazyPairFeatures(_LazyObjects):
     features] entry per pair) kept as the supporters' key-point index arrays; entry i becomes two object arrays of
     Feature when it is read.  kp_pairs[i]: int[n_i, 4] (L_i, R_i, L_{i+1}, R_{i+1}); xy_frames[f]: float32[2, n, 2]."""
 
-    def __init__(self, kp_pairs, xy_frames):
+    def __init__(self, kp_pairs, xy_frames, flat=None):
         self.kp_pairs, self.xy_frames = kp_pairs, xy_frames
+        self.flat = flat            # optional (int32[M,4], int64[P+1]): the same supporters in one piece, for chain_tracks
         super().__init__(len(kp_pairs), self._make)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["flat"] = None        # kp_pairs holds the same rows; a saved database does not need them twice
+        return state
 
     def _make(self, i):
         kp = self.kp_pairs[i]
@@ -399,7 +405,7 @@ class ArrayDataBase(DataBase):
             lazy = table
             inliers_percentage, global_cam_trans, relative_cam_trans = args
             kp_pairs, xy_frames = lazy.kp_pairs, lazy.xy_frames
-            table = tracks.chain_tracks(kp_pairs, xy_frames)
+            table = tracks.chain_tracks(kp_pairs, xy_frames, flat=lazy.flat)
         else:
             lazy = None
             kp_pairs, xy_frames, inliers_percentage, global_cam_trans, relative_cam_trans = args

@@ -68,9 +68,14 @@ class ArrayDetections:
 
     def arrays(self, frames):
         frames = np.asarray(frames)
-        d = np.zeros((len(frames), 2, self.desc.shape[2], 64), np.uint8)
-        d[..., :self.desc.shape[3]] = self.desc[frames]
-        return d, np.ascontiguousarray(self.xy[frames]), np.ascontiguousarray(self.count[frames])
+        if len(frames) and np.array_equal(frames, np.arange(frames[0], frames[0] + len(frames))):
+            frames = slice(int(frames[0]), int(frames[0]) + len(frames))       # a run of frames: views, no 1 GB copy
+        desc = self.desc[frames]
+        if desc.shape[3] != 64:
+            d = np.zeros(desc.shape[:3] + (64,), np.uint8)
+            d[..., :desc.shape[3]] = desc
+            desc = d
+        return desc, np.ascontiguousarray(self.xy[frames]), np.ascontiguousarray(self.count[frames])
 
 
 def _cuda(a, dtype=None):
@@ -595,11 +600,13 @@ def find_features_in_consecutive_frames_whole_movie(first_left_ex_cam_mat=M1, mo
     f0, f1 = pipeline.consecutive_pairs(n)
     res, xy, kp = track_pairs_arrays(np.arange(n), f0, f1, seeds)
     _check_pairs(res)
-    sup = tracks.supporters_from_shard(res.stats, res.mask, kp)
+    flat, ptr = tracks.supporters_flat(res.stats, res.mask, kp)
+    sup = [flat[ptr[p]:ptr[p + 1]] for p in range(n - 1)]
     T = res.stats[:, 0].astype(np.int64)
     percs = (100 * res.stats[:, 1].astype(np.int64) / T).tolist()          # :923, true division of Python ints
-    rel = [first_left_ex_cam_mat] + [res.pose[p] if res.ok[p] else None for p in range(n - 1)]
-    return LazyPairFeatures(sup, xy), percs, convert_trans_from_rel_to_global(rel), rel
+    ok = res.ok
+    rel = [first_left_ex_cam_mat] + [res.pose[p] if ok[p] else None for p in range(n - 1)]
+    return LazyPairFeatures(sup, xy, flat=(flat, ptr)), percs, convert_trans_from_rel_to_global(rel), rel
 
 
 def whole_movie_database(first_left_ex_cam_mat=M1, movie_len=None, seeds=None):

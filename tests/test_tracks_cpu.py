@@ -141,3 +141,39 @@ def test_array_database_saves_and_loads(tmp_path):
     back = types.load(path)
     _assert_same(obj, back)
     assert np.array_equal(back.get_relative_cam_trans(), arr.get_relative_cam_trans())
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_native_chaining_equals_the_numpy_restatement_field_by_field(seed):
+    """slam_chain_tracks (csrc/tracks_host.cpp) against the per-pair numpy version of the same rule on a movie-sized
+    case: ragged pairs, empty pairs, long tracks; coordinates taken from one [F, 2, n_max, 2] block or a list of frames."""
+    rng = np.random.default_rng(seed)
+    n_frames, n_kp = 300, 2048
+    xy = rng.random((n_frames, 2, n_kp, 2)).astype(np.float32) * 1200
+    kp_pairs, prev = [], np.empty(0, np.int64)
+    for i in range(n_frames - 1):
+        n = int(rng.integers(0, 1500)) if i % 97 != 50 else 0
+        # most supporters continue a key-point the previous pair ended on, as in a real movie
+        keep = rng.permutation(prev)[:int(0.8 * min(n, len(prev)))]
+        fresh = rng.permutation(np.setdiff1d(np.arange(n_kp), keep))[:n - len(keep)]
+        l0 = np.sort(np.concatenate([keep, fresh]))
+        l1 = rng.choice(n_kp, len(l0), replace=False)
+        kp_pairs.append(np.stack([l0, rng.integers(0, n_kp, len(l0)), l1, rng.integers(0, n_kp, len(l0))], 1).astype(np.int32).reshape(-1, 4))
+        prev = l1
+    want = tracks.chain_tracks_numpy(kp_pairs, xy)
+    for got in (tracks.chain_tracks(kp_pairs, xy), tracks.chain_tracks(kp_pairs, [xy[f] for f in range(n_frames)]),
+                tracks.chain_tracks(kp_pairs, xy, flat=tracks.flatten_pairs(kp_pairs))):
+        assert (got.n_frames, got.n_tracks) == (want.n_frames, want.n_tracks) and want.track_len().max() > 5
+        for name in ("track_ptr", "obs_frame", "obs_kp", "obs_xy", "frame_ptr", "frame_tracks"):
+            a, b = getattr(got, name), getattr(want, name)
+            assert a.dtype == b.dtype and np.array_equal(a, b), name
+
+
+def test_native_chaining_refuses_bad_indices():
+    xy = np.zeros((2, 2, 8, 2), np.float32)
+    with pytest.raises(IndexError):
+        tracks.chain_tracks([np.array([[1, 0, 9, 0]])], xy)
+    with pytest.raises(IndexError):
+        tracks.chain_tracks([np.array([[1, 0, 2, -1]])], xy)
+    with pytest.raises(ValueError):
+        tracks.chain_tracks([np.array([[1, 0, 2, 0]])], xy, flat=(np.array([[1, 0, 2, 0]], np.int32), np.array([0, 2])))
