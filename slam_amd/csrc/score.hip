@@ -52,21 +52,25 @@ __device__ __forceinline__ bool within(const double *P, double x, double y, doub
 }
 
 // Fast classification of the same test: 1 = inside, 0 = outside, -1 = too close to the threshold to call.
-// The homogeneous coordinates are the exact ones above; only the two divisions and the square root are replaced by
-// a refined reciprocal and a comparison of the squared distance against [thr^2 (1 - 1e-9), thr^2 (1 + 1e-9)].  The
-// approximation error is ~1e-13 relative, four orders below the band, so every decisive answer equals the exact
-// test's; the rare undecided point (and any NaN) takes the exact path.  Halves the FP64 instruction count.
+// The homogeneous coordinates are the exact ones above; the two divisions and the square root are avoided by testing
+//     (hx - u hz)^2 + (hy - v hz)^2   against   thr^2 hz^2 (1 -+ 1e-9)
+// (the reference's inequality multiplied by hz^2 >= 0; it has no positive-depth test, so the sign of hz does not
+// matter).  hx - u hz is ONE fused multiply-add, hence correctly rounded however much cancels, and both sides carry a
+// relative error of a few 1e-16: five orders below the band, so every decisive answer equals the exact test's.  The
+// undecided point takes the exact path, and so does everything irregular: a NaN or infinity anywhere makes both
+// comparisons false; hz = 0 gives thresholds -+TINY, which no square reaches from the right side; TINY also keeps
+// a tiny hz (hz^2 underflowing) from deciding anything, since products lose at most ~1e-322 to underflow.
+// (r1 used a Newton-refined hardware reciprocal here: 5 more instructions, one of them quarter rate.)
+constexpr double TINY = 1e-250;
+
 __device__ __forceinline__ int within_fast(const double *P, double x, double y, double z, double u, double v, double lo,
                                            double hi) {
     const double hx = fma(z, P[2], fma(y, P[1], x * P[0])) + P[3];
     const double hy = fma(z, P[6], fma(y, P[5], x * P[4])) + P[7];
     const double hz = fma(z, P[10], fma(y, P[9], x * P[8])) + P[11];
-    double r = __builtin_amdgcn_rcp(hz);
-    r = fma(r, fma(-hz, r, 1.0), r);
-    r = fma(r, fma(-hz, r, 1.0), r);
-    const double dx = fma(hx, r, -u), dy = fma(hy, r, -v);      // fused: this path only classifies against the band
-    const double q = fma(dx, dx, dy * dy);
-    return q < lo ? 1 : (q > hi ? 0 : -1);
+    const double a = fma(-u, hz, hx), b = fma(-v, hz, hy);       // fused: this path only classifies against the band
+    const double q = fma(a, a, b * b), z2 = hz * hz;
+    return q < fma(lo, z2, -TINY) ? 1 : (q > fma(hi, z2, TINY) ? 0 : -1);
 }
 
 // Both cameras at once for a rectified pair (RECT, decided on the host from K and M2, see rectified_rig): with
@@ -82,13 +86,11 @@ __device__ __forceinline__ int within_fast_rect(const double *Pl, double pr3, do
     const double hxl = sx + Pl[3], hxr = sx + pr3;
     const double hy = fma(z, Pl[6], fma(y, Pl[5], x * Pl[4])) + Pl[7];
     const double hz = fma(z, Pl[10], fma(y, Pl[9], x * Pl[8])) + Pl[11];
-    double r = __builtin_amdgcn_rcp(hz);
-    r = fma(r, fma(-hz, r, 1.0), r);
-    r = fma(r, fma(-hz, r, 1.0), r);
-    const double dxl = fma(hxl, r, -ul), dyl = fma(hy, r, -vl), dxr = fma(hxr, r, -ur), dyr = fma(hy, r, -vr);
-    const double ql = fma(dxl, dxl, dyl * dyl), qr = fma(dxr, dxr, dyr * dyr);
-    if (ql > hi || qr > hi) return 0;
-    return (ql < lo && qr < lo) ? 1 : -1;
+    const double al = fma(-ul, hz, hxl), bl = fma(-vl, hz, hy), ar = fma(-ur, hz, hxr), br = fma(-vr, hz, hy);
+    const double ql = fma(al, al, bl * bl), qr = fma(ar, ar, br * br), z2 = hz * hz;
+    const double lo2 = fma(lo, z2, -TINY), hi2 = fma(hi, z2, TINY);
+    if (ql > hi2 || qr > hi2) return 0;
+    return (ql < lo2 && qr < lo2) ? 1 : -1;
 }
 
 constexpr int SB = 256;   // 4 waves per workgroup, all on the same segment (shared L1 footprint)
@@ -245,6 +247,27 @@ __global__ __launch_bounds__(SB) void score_lanes_kernel(Mat33 K, Mat34 M2, cons
     const double *Xs = X + (size_t)seg * seg_stride * 3;
     const XY4 *obs = xy1 + (size_t)seg * seg_stride;
     const double lo = thr < 0.0 ? -1.0 : thr * thr * (1.0 - 1e-9), hi = thr < 0.0 ? -1.0 : thr * thr * (1.0 + 1e-9);
+    // fast classification of point i of the tile: 1 inside, 0 outside, -1 undecided
+    auto classify = [&](int i) -> int {
+        const double *q = pts + i * 7;
+        if (RECT) return within_fast_rect(Pl, Pr[3], q[0], q[1], q[2], q[3], q[4], q[5], q[6], lo, hi);
+        const int fl = within_fast(Pl, q[0], q[1], q[2], q[3], q[4], lo, hi);
+        const int fr = within_fast(Pr, q[0], q[1], q[2], q[5], q[6], lo, hi);
+        return (fl == 0 || fr == 0) ? 0 : ((fl == 1 && fr == 1) ? 1 : -1);
+    };
+    // the reference's arithmetic, literally (points within 1e-9 of the radius, non-finite values)
+    auto exact = [&](int i) -> bool {
+        const double *q = pts + i * 7;
+        if (RECT) {
+            // the right matrix is the left one except element (0, 3) (see within_fast_rect): 13 live doubles, not 24
+            double R[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) R[e] = Pl[e];
+            R[3] = Pr[3];
+            return within(Pl, q[0], q[1], q[2], q[3], q[4], thr) && within(R, q[0], q[1], q[2], q[5], q[6], thr);
+        }
+        return within(Pl, q[0], q[1], q[2], q[3], q[4], thr) && within(Pr, q[0], q[1], q[2], q[5], q[6], thr);
+    };
     int total = 0;
     for (int base = 0; base < n; base += LT) {
         if (base) __syncthreads();                     // the previous tile has been consumed
@@ -261,22 +284,33 @@ __global__ __launch_bounds__(SB) void score_lanes_kernel(Mat33 K, Mat34 M2, cons
             q[6] = (double)c.w;
         }
         __syncthreads();
-        const int m = min(LT, n - base);
+        const int m = __builtin_amdgcn_readfirstlane(min(LT, n - base));
         if (live) {
-            for (int i = 0; i < m; ++i) {
-                const double *q = pts + i * 7;
-                const double x = q[0], y = q[1], z = q[2], ul = q[3], vl = q[4], ur = q[5], vr = q[6];
-                int f;
-                if (RECT) {
-                    f = within_fast_rect(Pl, Pr[3], x, y, z, ul, vl, ur, vr, lo, hi);
-                } else {
-                    const int fl = within_fast(Pl, x, y, z, ul, vl, lo, hi);
-                    const int fr = within_fast(Pr, x, y, z, ur, vr, lo, hi);
-                    f = (fl == 0 || fr == 0) ? 0 : ((fl == 1 && fr == 1) ? 1 : -1);
+            // PU points per step: their LDS reads are in flight together and the (rare) undecided ones are settled once
+            // per step, one branch per PU points instead of one per point (PU = 3: 116 VGPRs, 4 wavefronts per SIMD;
+            // 4 takes 184.  Two or four hypotheses per lane, to halve the broadcast reads, were slower: 3.6 / 3.8 ms
+            // against 2.6 ms on the 10 000-hypothesis configuration -- the kernel is FP64-issue bound, not LDS bound.)
+            constexpr int PU = 3;
+            int i = 0;
+            for (; i + PU <= m; i += PU) {
+                int f[PU], cnt = 0;
+                bool undecided = false;
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    f[u] = classify(i + u);
+                    cnt += f[u] == 1 ? 1 : 0;
+                    undecided |= f[u] < 0;
                 }
-                bool in = f == 1;
-                if (f < 0) in = within(Pl, x, y, z, ul, vl, thr) && within(Pr, x, y, z, ur, vr, thr);
-                total += in ? 1 : 0;
+                if (undecided) {
+#pragma unroll
+                    for (int u = 0; u < PU; ++u)
+                        if (f[u] < 0 && exact(i + u)) ++cnt;
+                }
+                total += cnt;
+            }
+            for (; i < m; ++i) {
+                const int f = classify(i);
+                total += (f == 1 || (f < 0 && exact(i))) ? 1 : 0;
             }
         }
     }
