@@ -431,6 +431,74 @@ def test_scoring_many_hypotheses_per_segment_lane_per_hypothesis_kernel(rig, xy_
     assert (want[-1, 2::3] == 0).mean() > 0.9 and (want[-1, 1::3] > 0).any()      # garbage / partly-off hypotheses are there
 
 
+@pytest.mark.parametrize("rig", ["unit_rectified", "general"])
+def test_scoring_threshold_edge_cases_of_the_division_free_classification(rig):
+    """The fast consensus test compares (hx - u hz)^2 + (hy - v hz)^2 with thr^2 hz^2 (1 -+ 1e-9) and leaves everything
+    else to the reference's divide + sqrt arithmetic.  Points built to sit where that hand-over must happen: exactly on
+    the radius and a few ulps either side, on the camera plane (hz = 0, with and without hx = hy = 0), depths whose
+    square underflows or overflows, negative depth, non-finite points and observations; radius 4, 0 and negative.
+    Both counting kernels and the mask kernel against the oracle."""
+    if rig == "unit_rectified":
+        # hx = x, hy = y, hz = z exactly, in both cameras (zero baseline: a tiny depth then projects to modest pixel
+        # coordinates in the right camera too; the reference's own rounding error in hx / hz is eps * |u|, so its
+        # decisions are only meaningful, and only reproduced, for observations of image-like magnitude, DESIGN.md section 5)
+        K, M2 = np.eye(3), np.hstack([np.eye(3), np.zeros((3, 1))])
+    else:
+        K, M2 = _general_rig()
+    T = np.hstack([np.eye(3), np.zeros((3, 1))])
+    u, v = 10.0, 5.0
+    pts = []          # (X, left obs, right obs)
+
+    def add(x, y, z, ul=u, vl=v, ur=None, vr=v):
+        pts.append(((x, y, z), (ul, vl), ((x / z if z != 0.0 and np.isfinite(z) and np.isfinite(x) else 0.0) if ur is None else ur, vr)))
+
+    for d in (0.0, 2.0 ** -50, -2.0 ** -50, 2.0 ** -44, -2.0 ** -44, 1e-8, -1e-8, 1e-3, -1e-3):
+        add(28.0 + d, 10.0, 2.0)                       # left distance 4 + d / 2: on the radius, ulps and 1e-9 either side
+        add(20.0, 10.0, 2.0, ur=14.0 + d, vr=5.0)      # same in the right camera: 20 / 2 = 10, 4 px from 14
+    add(20.0, 10.0, 2.0)                               # dead centre: distance 0 (the one supporter at radius 0)
+    add(3.0, 1.0, 0.0)                                 # on the camera plane: inf
+    add(0.0, 0.0, 0.0)                                 # 0 / 0
+    add(12e-170, 5e-170, 1e-170)                       # hz^2 underflows; projects to (12, 5): inside by 2 px in both cameras
+    add(12e-170, 5e-170, 1e-170, ur=17.0)              # ... right camera 5 px off
+    add(12e-140, 5e-140, 1e-140)
+    add(12e200, 5e200, 1e200)                          # hz^2 overflows; inside both
+    add(14.1e200, 5e200, 1e200)                        # ... outside by 0.1 px
+    add(-24.0, -10.0, -2.0)                            # negative depth projects to (12, 5): the reference counts it
+    add(np.inf, 1.0, 2.0)
+    add(1.0, np.nan, 2.0)
+    add(24.0, 10.0, np.inf)
+    add(24.0, 10.0, 2.0, ul=np.nan)
+    add(24.0, 10.0, 2.0, ur=np.inf)
+    add(24.0, 10.0, 2.0, vr=np.nan)
+    n, stride, H = len(pts), 64, 320
+    X = np.array([p[0] for p in pts])
+    l1, r1 = np.array([p[1] for p in pts]), np.array([p[2] for p in pts])
+    Xs = np.zeros((1, stride, 3))
+    Xs[0, :n] = X
+    xy1 = np.zeros((1, stride, 4))
+    xy1[0, :n] = np.hstack([l1, r1])
+    Ts = np.repeat(T[None, None], H, 1)
+    Ts[0, 1::2, 0, 3] = 2.0 ** -45                     # every other hypothesis: shifted by ulps, so hx differs in the last bits
+    status = np.ones((1, H), np.uint8)
+    for acc, thr in ((2, 4.0), (0, 0.0), (None, -1.0)):
+        with np.errstate(all="ignore"):
+            want = np.zeros((H, n), bool) if acc is None else np.array([orc.consensus_match(K, Ts[0, h], M2, X, l1, r1, acc) for h in range(H)])
+        args = (K, M2, dev(Xs), dev(xy1), dev(np.array([n], np.int32)), dev(Ts), dev(status), thr)
+        cnt, _ = ops.score_hypotheses(*args)                                  # lane per hypothesis
+        cnt_w, mask = ops.score_hypotheses(*args, want_mask=True)             # wavefront per hypothesis, masks
+        cnt2, _ = ops.score_hypotheses(K, M2, dev(Xs), dev(xy1), dev(np.array([n], np.int32)), dev(Ts[:, :40]), dev(status[:, :40]), thr)
+        assert np.array_equal(ops.mask_words_to_bool(mask.cpu().numpy()[0], n), want), thr
+        assert np.array_equal(cnt.cpu().numpy()[0], want.sum(1)) and np.array_equal(cnt_w.cpu().numpy()[0], want.sum(1)), thr
+        assert np.array_equal(cnt2.cpu().numpy()[0], want.sum(1)[:40]), thr
+        if rig == "unit_rectified" and acc == 2:
+            # on the radius counts (the reference's test is <=); 2^-45 px outside does not; 2^-45 px inside does
+            assert want[0, 0] and want[0, 1] and not want[0, 6] and not want[0, 7] and want[0, 8] and want[0, 9]
+            assert want[0, 18] and not want[0, 19] and not want[0, 20] and want[0, 21] and not want[0, 22] and want[0, 23]
+            assert want[0, 24] and not want[0, 25] and want[0, 26] and not want[0, 27:].any()
+        if rig == "unit_rectified" and acc == 0:
+            assert want[0].sum() >= 1
+
+
 def test_device_sample_stream_equals_numpy():
     """slam_randint_draws against np.random.seed / np.random.randint itself: bounds at and around powers of two (the
     rejection rate's extremes), bound 1 (numpy consumes nothing), ranges that start mid-stream and straddle the 624-word
