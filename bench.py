@@ -69,8 +69,9 @@ def parse(argv=None):
     ap.add_argument("--taper", type=float, default=1.0, help="each chunk's size relative to the previous one (1 = equal)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the PCIe-inclusive leg (reported beside, never as, value)")
     ap.add_argument("--no-dropin", action="store_true", help="skip timing the reference-shaped whole-movie call")
-    ap.add_argument("--match-rule", choices=("ocv_legacy", "mutual"), default="ocv_legacy",
-                    help="cross-check rule of the matcher (DESIGN.md section 2); the headline uses the default")
+    ap.add_argument("--match-rule", choices=("ocv_legacy", "mutual", "knn"), default="ocv_legacy",
+                    help="cross-check rule of the matcher (DESIGN.md section 2), or knn = the reference's REGULAR KNN "
+                         "method (two nearest + ratio 0.6, utills.py:112-119); the headline uses the default")
     return ap.parse_args(argv)
 
 
@@ -173,6 +174,9 @@ def hot_path_config(args, **kw):
         kw["first_chunk"] = args.first_chunk
     if args.match_rule == "mutual":
         kw["crosscheck_rule"] = "mutual"
+    if args.match_rule == "knn":
+        from slam_amd.config import REGULAR_KNN
+        kw["match_method"] = REGULAR_KNN
     return HotPathConfig(**kw)
 
 
@@ -321,7 +325,8 @@ def run_trajectory(args, rk: Rank):
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u32 popcount + f64",
         "data": "synthetic",
         "config": {"workload": workload, "descriptor_bytes": 61, "norm": "NORM_HAMMING2",
-                   "match": "cross-check brute force" + (" (mutual rule)" if args.match_rule == "mutual" else ""),
+                   "match": {"ocv_legacy": "cross-check brute force", "mutual": "cross-check brute force (mutual rule)",
+                             "knn": "kNN (k = 2) + ratio 0.6"}[args.match_rule],
                    "ransac": "adaptive (prob 0.9999, cap 1000), seeds 1000+pair", "parallelism": f"frame-range x{world}"},
         "roofline": matcher_roofline(args, leg),
         "stage_ms": stage_dict(leg["stage_ms"]),
