@@ -11,6 +11,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -
 f=$(find $out -name '*kernel_stats.csv' | sort | sed -n 1p)
 python - "$f" <<'PY'
 import csv, sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:9]:
+for r in list(csv.DictReader(open(sys.argv[1])))[:16]:
     print(f"{r['Name'][:70]:70s} calls {r['Calls']:>6s}  total {float(r['TotalDurationNs'])/1e6:9.3f} ms  avg {float(r['AverageNs'])/1e3:9.1f} us")
 PY
