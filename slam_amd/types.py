@@ -189,6 +189,18 @@ class Track:
         return self._sorted_ids[0]
 
 
+def _pose_array(poses):
+    """np.array(poses) as the reference does (DataBase.py:45); a list holding None (a pair without a pose) becomes an
+    object array instead of the ValueError numpy >= 1.24 raises for ragged input."""
+    try:
+        return np.array(poses)
+    except ValueError:
+        out = np.empty(len(poses), dtype=object)
+        for i, p in enumerate(poses):
+            out[i] = p
+        return out
+
+
 def save(path, db):
     """DataBase.py:15-22."""
     with open(path, "wb") as fh:
@@ -221,7 +233,7 @@ class DataBase:
         self._last_kpts = {}
         self._inliers_percentage = inliers_percentage
         self._pair_features = prev_and_next_frame_features
-        self._relative = np.array(relative_cam_trans)
+        self._relative = _pose_array(relative_cam_trans)
         self.create_db(prev_and_next_frame_features, global_cam_trans)
 
     def create_db(self, prev_and_next_frame_features, global_cam_trans):
@@ -412,7 +424,7 @@ class ArrayDataBase(DataBase):
         self._table = table
         self._kp_pairs, self._xy_frames = kp_pairs, xy_frames
         self._inliers_percentage = inliers_percentage
-        self._relative = np.array(relative_cam_trans)
+        self._relative = _pose_array(relative_cam_trans)
         self._last_kpts = {}
         fp, ft = table.frame_ptr, table.frame_tracks
         frames = np.empty(table.n_frames, dtype=object)
@@ -461,3 +473,29 @@ class ArrayDataBase(DataBase):
 
     def add_track(self, track):
         raise TypeError("ArrayDataBase is built whole; use DataBase to grow a database track by track")
+
+    def save_arrays(self, path):
+        """The database as one .npz of plain arrays (supporters, coordinates, poses, inlier percentages): a file that
+        np.load reads with allow_pickle=False, for callers who do not want to unpickle (`load_arrays` rebuilds it)."""
+        from . import tracks
+        flat, ptr = self._pair_features.flat or tracks.flatten_pairs(self._kp_pairs)
+        xy = tracks._xy_block(self._xy_frames, self._table.n_frames)
+        glob = np.array([f.get_ex_cam_mat() for f in self._frames], np.float64)
+        rel = self._relative
+        rel_ok = np.array([r is not None for r in rel], bool)
+        rel_arr = np.array([np.asarray(r, np.float64) if r is not None else np.full((3, 4), np.nan) for r in rel])
+        np.savez(path, format=np.array("slam_amd.ArrayDataBase/1"), supporters=flat, pair_ptr=ptr, xy=xy, global_trans=glob,
+                 relative_trans=rel_arr, relative_ok=rel_ok, inliers_percentage=np.asarray(self._inliers_percentage, np.float64))
+
+    @staticmethod
+    def load_arrays(path):
+        from . import tracks
+        with np.load(path, allow_pickle=False) as z:
+            if str(z["format"]) != "slam_amd.ArrayDataBase/1":
+                raise ValueError(f"{path}: not an ArrayDataBase array file")
+            flat, ptr, xy = z["supporters"], z["pair_ptr"], z["xy"]
+            glob, rel_arr, rel_ok, percs = z["global_trans"], z["relative_trans"], z["relative_ok"], z["inliers_percentage"]
+        kp_pairs = [flat[ptr[i]:ptr[i + 1]] for i in range(len(ptr) - 1)]
+        rel = [rel_arr[i] if rel_ok[i] else None for i in range(len(rel_arr))]
+        lazy = LazyPairFeatures(kp_pairs, xy, flat=(flat, ptr))
+        return ArrayDataBase(lazy, percs.tolist(), list(glob), rel)

@@ -177,3 +177,31 @@ def test_native_chaining_refuses_bad_indices():
         tracks.chain_tracks([np.array([[1, 0, 2, -1]])], xy)
     with pytest.raises(ValueError):
         tracks.chain_tracks([np.array([[1, 0, 2, 0]])], xy, flat=(np.array([[1, 0, 2, 0]], np.int32), np.array([0, 2])))
+
+
+def test_array_database_array_file_round_trip(tmp_path):
+    """ArrayDataBase.save_arrays / load_arrays: a file of plain arrays (np.load with allow_pickle=False), equal to the
+    database it was written from, with a pair whose pose is None."""
+    kp, xy = _golden_pairs()
+    n = len(kp) + 1
+    glob = [np.hstack([np.eye(3), np.array([[0.0], [0.0], [-1.0 * f]])]) for f in range(n)]
+    rel = [np.hstack([np.eye(3), np.array([[0.0], [0.0], [-1.0]])]) for _ in range(n)]
+    rel[3] = None
+    percs = [50.0 + i for i in range(len(kp))]
+    arr = ArrayDataBase(tracks.chain_tracks(kp, xy), kp, xy, percs, glob, rel)
+    path = str(tmp_path / "db.npz")
+    arr.save_arrays(path)
+    with np.load(path, allow_pickle=False) as z:                     # nothing in the file needs pickle
+        assert set(z.files) >= {"supporters", "pair_ptr", "xy", "global_trans", "relative_trans", "inliers_percentage"}
+    back = ArrayDataBase.load_arrays(path)
+    obj, _ = _both(kp, xy)
+    _assert_same(obj, back)
+    t0, t1 = arr.get_table(), back.get_table()
+    for name in ("track_ptr", "obs_frame", "obs_kp", "obs_xy", "frame_ptr", "frame_tracks"):
+        assert np.array_equal(getattr(t0, name), getattr(t1, name)), name
+    r0, r1 = arr.get_relative_cam_trans(), back.get_relative_cam_trans()
+    assert len(r0) == len(r1) and r1[3] is None and all(np.array_equal(a, b) for i, (a, b) in enumerate(zip(r0, r1)) if i != 3)
+    assert list(back._inliers_percentage) == percs
+    with pytest.raises(ValueError):
+        np.savez(str(tmp_path / "other.npz"), format=np.array("something else"))
+        ArrayDataBase.load_arrays(str(tmp_path / "other.npz"))
