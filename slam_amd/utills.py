@@ -560,9 +560,10 @@ def _source_arrays(frames):
     return desc, xy, count
 
 
-def track_pairs_arrays(frames, pair_f0, pair_f1, seeds=None):
+def track_pairs_arrays(frames, pair_f0, pair_f1, seeds=None, host_kp=True):
     """Batched core of the drivers below: frames = movie indices, pair_f0/f1 = positions in `frames`.
-    Returns (ShardResult, xy float32[F,2,n_max,2], tracked key-point indices int32[P,n_max,4])."""
+    Returns (ShardResult, xy float32[F,2,n_max,2], tracked key-point indices int32[P,n_max,4]); with host_kp=False the
+    result keeps the supporter masks as bit words and the indices stay on the device (ShardResult.tracked_kp)."""
     desc, xy, count = _source_arrays(frames)
     F, _, n_max, _ = desc.shape
     P = len(pair_f0)
@@ -570,8 +571,8 @@ def track_pairs_arrays(frames, pair_f0, pair_f1, seeds=None):
         seeds = np.random.randint(0, 2 ** 32, P, dtype=np.uint64)      # one draw from the global stream per pair
     trk = pipeline.ShardTracker(F, P, n_max, _hot_path_config())
     res = trk.run(_cuda(desc.reshape(2 * F, n_max, 64)), _cuda(xy.reshape(2 * F, n_max, 2)), _cuda(count.reshape(2 * F)),
-                  np.asarray(pair_f0, np.int32), np.asarray(pair_f1, np.int32), seeds)
-    return res, xy, res.tracked_kp.cpu().numpy()
+                  np.asarray(pair_f0, np.int32), np.asarray(pair_f1, np.int32), seeds, unpack_mask=host_kp)
+    return res, xy, (res.tracked_kp.cpu().numpy() if host_kp else None)
 
 
 def _features_of(kp_lr, xy_frame):
@@ -598,9 +599,9 @@ def find_features_in_consecutive_frames_whole_movie(first_left_ex_cam_mat=M1, mo
     pass).  DataBase(...) recognises it and chains the tracks on the index arrays (types.ArrayDataBase)."""
     n = movie_len if movie_len is not None else min(MOVIE_LEN, len(DETECTIONS)) if hasattr(DETECTIONS, "__len__") else MOVIE_LEN
     f0, f1 = pipeline.consecutive_pairs(n)
-    res, xy, kp = track_pairs_arrays(np.arange(n), f0, f1, seeds)
+    res, xy, _ = track_pairs_arrays(np.arange(n), f0, f1, seeds, host_kp=False)
     _check_pairs(res)
-    flat, ptr = tracks.supporters_flat(res.stats, res.mask, kp)
+    flat, ptr = ops.compact_supporters(res.mask, res.stats[:, 0], res.tracked_kp)
     sup = [flat[ptr[p]:ptr[p + 1]] for p in range(n - 1)]
     T = res.stats[:, 0].astype(np.int64)
     percs = (100 * res.stats[:, 1].astype(np.int64) / T).tolist()          # :923, true division of Python ints

@@ -171,3 +171,23 @@ def test_loop_candidates_through_the_detection_cache(golden, movie):
     assert got5 == want5 and got6 == want6 and len(want5) + len(want6) > 0
     assert sorted(counting.calls) == [1, 2, 5, 6]           # candidates 1 and 2 were detected once, not twice
     assert cache.hits == 2 and cache.misses == 4
+
+
+def test_supporters_compacted_on_the_device_equal_the_host_compaction(movie):
+    """ops.compact_supporters (device gather + one pinned copy, what the whole-movie driver uses) against
+    tracks.supporters_flat on a host copy of the same shard: same rows, same order, same row pointer; and a shard
+    without a single supporter."""
+    import torch
+    from slam_amd import ops, pipeline, tracks
+    n = len(U.DETECTIONS)
+    f0, f1 = pipeline.consecutive_pairs(n)
+    res, xy, kp = U.track_pairs_arrays(np.arange(n), f0, f1, seeds=np.arange(n - 1) + 5)
+    want_flat, want_ptr = tracks.supporters_flat(res.stats, res.mask, kp)
+    words = ops.bool_to_mask_words(res.mask, res.mask.shape[1])
+    flat, ptr = ops.compact_supporters(words, res.stats[:, 0], res.tracked_kp)
+    assert flat.dtype == np.int32 and np.array_equal(flat, want_flat) and np.array_equal(ptr, want_ptr) and len(flat) > 100
+    flat0, ptr0 = ops.compact_supporters(np.zeros_like(words), res.stats[:, 0], res.tracked_kp)
+    assert flat0.shape == (0, 4) and not ptr0.any()
+    # bits beyond the tracked count are ignored, as on the host
+    flat1, ptr1 = ops.compact_supporters(np.full_like(words, -1), res.stats[:, 0], res.tracked_kp)
+    assert np.array_equal(np.diff(ptr1), res.stats[:, 0])
