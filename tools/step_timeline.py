@@ -1,7 +1,7 @@
 """Timeline of one bench step from a rocprofv3 --kernel-trace --memory-copy-trace run (csv): kernels and copies of the
 step that starts at the N-th matcher launch, with the gaps between consecutive GPU activities.
 
-    python tools/step_timeline.py <trace dir> [step index]
+    python tools/step_timeline.py <trace dir> [step index] [matcher launches per step: 2 = the default two chunks]
 """
 import csv
 import glob
@@ -15,7 +15,7 @@ def main():
     cf = glob.glob(d + "/*/*memory_copy_trace.csv")          # optional: a --kernel-trace only run has none
     cop = list(csv.DictReader(open(cf[0]))) if cf else []
     al = sorted(int(r["Start_Timestamp"]) for r in rows if "allpairs" in r["Kernel_Name"])
-    lanes = 2
+    lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     t_a, t_b = al[step * lanes], al[(step + 1) * lanes]
     ev = []
     for r in rows:
