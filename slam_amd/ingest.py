@@ -66,6 +66,12 @@ class HostSlot:
     count: np.ndarray    # int32  [F, 2]
 
 
+# A shard goes up in pieces of this many bytes, not as one 0.9 GB copy: the tracker of the shard before it issues small
+# host-to-device copies between its kernels (set-up arrays, the winners of a RANSAC round) and waits for them; behind one
+# big copy on the same DMA queue each of them would wait for the whole upload.
+PIECE_BYTES = int(__import__("os").environ.get("SLAM_INGEST_PIECE_BYTES", 32 << 20))
+
+
 class ShardStager:
     """Two pinned host slots + two device slots for shards of up to n_frames frames, and the copy stream between them.
 
@@ -78,10 +84,11 @@ class ShardStager:
 
     Device memory: 2 x (2F x n_max x 72 B + 8F) - 2 GB for two 3450-frame shards of 2048-row images."""
 
-    def __init__(self, n_frames: int, n_max: int, n_slots: int = 2):
+    def __init__(self, n_frames: int, n_max: int, n_slots: int = 2, piece_bytes: int = PIECE_BYTES):
         if n_max % 64:
             raise ValueError("n_max must be a multiple of 64")
         self.n_frames, self.n_max, self.n_slots = n_frames, n_max, n_slots
+        self.piece_bytes = int(piece_bytes)
         self.dev = ops.device()
         self.copy_stream = torch.cuda.Stream(device=self.dev)
         F = n_frames
@@ -115,7 +122,10 @@ class ShardStager:
             if self._released[k] is not None:
                 self.copy_stream.wait_event(self._released[k])     # compute still reading the device slot
             for h, d in zip(self._h[k], self._d[k]):
-                d[:2 * F].copy_(h[:2 * F], non_blocking=True)
+                rows = max(1, self.piece_bytes // max(1, h[0].numel() * h.element_size()))
+                for a in range(0, 2 * F, rows):                    # in pieces: see piece_bytes
+                    b = min(2 * F, a + rows)
+                    d[a:b].copy_(h[a:b], non_blocking=True)
             self._uploaded[k].record(self.copy_stream)
         self._frames[k] = F
 
