@@ -64,6 +64,82 @@ def gather_shard_results(pose_local: np.ndarray, stats_local: np.ndarray, n_pair
     return pose, stats
 
 
+def _coll_device(device=None):
+    if device is not None:
+        return device
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def gather_ragged_rows(local_rows: np.ndarray, local_counts: np.ndarray, n_units_total: int, device=None):
+    """Variable-length row lists per unit (the supporters' key-point rows of every frame pair: what the track database
+    on the other side of the path is built from, DataBase.py:39-51).  local_rows [m, ...]: this rank's rows, unit after
+    unit; local_counts int[p]: rows per unit of this rank's block (`block_range`).  Returns (rows of all units, unit
+    after unit, int64 row pointer [n_units_total + 1]) on every rank.  Two collectives: the counts, then the rows padded
+    to the largest block."""
+    if not dist.is_initialized():
+        ptr = np.zeros(len(local_counts) + 1, np.int64)
+        np.cumsum(local_counts, out=ptr[1:])
+        return local_rows, ptr
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = _coll_device(device)
+    counts = all_gather_rows(torch.from_numpy(np.ascontiguousarray(local_counts, dtype=np.int64).reshape(-1, 1)).to(dev),
+                             n_units_total, world, rank).cpu().numpy().reshape(-1)
+    ptr = np.zeros(n_units_total + 1, np.int64)
+    np.cumsum(counts, out=ptr[1:])
+    blocks = [block_range(n_units_total, r, world) for r in range(world)]
+    rows_of = [int(ptr[b] - ptr[a]) for a, b in blocks]
+    m_max = max(rows_of + [1])
+    local_rows = np.ascontiguousarray(local_rows)
+    if len(local_rows) != rows_of[rank]:
+        raise ValueError("local_rows does not hold sum(local_counts) rows")
+    pad = torch.zeros((m_max,) + local_rows.shape[1:], dtype=torch.from_numpy(local_rows[:0]).dtype, device=dev)
+    pad[:len(local_rows)] = torch.from_numpy(local_rows).to(dev)
+    out = torch.empty((world * m_max,) + tuple(pad.shape[1:]), dtype=pad.dtype, device=dev)
+    dist.all_gather_into_tensor(out, pad)
+    out = out.cpu().numpy()
+    return np.concatenate([out[r * m_max:r * m_max + rows_of[r]] for r in range(world)]), ptr
+
+
+def gather_frames(local_frames: np.ndarray, n_frames: int, device=None) -> np.ndarray:
+    """Per-frame arrays of a movie whose frames are held as `shard_frames` hands them out (rank r: the first frames of
+    its pairs plus one halo frame).  local_frames [fb - fa, ...] -> [n_frames, ...] on every rank: every rank
+    contributes the first frame of each of its pairs; the movie's last frame comes from the rank that owns the last
+    pair (its halo)."""
+    if not dist.is_initialized():
+        return local_frames
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = _coll_device(device)
+    a, b, _, _ = shard_frames(n_frames, rank, world)
+    mine = torch.from_numpy(np.ascontiguousarray(local_frames[:b - a])).to(dev)
+    body = all_gather_rows(mine, n_frames - 1, world, rank)
+    owner = max(r for r in range(world) if block_range(n_frames - 1, r, world)[1] > block_range(n_frames - 1, r, world)[0]) if n_frames > 1 else 0
+    last = (torch.from_numpy(np.ascontiguousarray(local_frames[b - a:b - a + 1])).to(dev) if rank == owner
+            else torch.empty((1,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=dev))
+    dist.broadcast(last, src=owner)
+    return torch.cat([body, last]).cpu().numpy()
+
+
+def max_over_ranks(value: int, device=None) -> int:
+    if not dist.is_initialized():
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=_coll_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def broadcast_array(a, shape, dtype, src=0, device=None) -> np.ndarray:
+    """One host array from rank `src` to every rank (the per-pair seeds drawn from rank 0's global random stream)."""
+    if not dist.is_initialized():
+        return np.asarray(a, dtype=dtype).reshape(shape)
+    dev = _coll_device(device)
+    if dist.get_rank() == src:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype).reshape(shape))).to(dev)
+    else:
+        t = torch.empty(shape, dtype=torch.from_numpy(np.empty(0, dtype)).dtype, device=dev)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
 def run_sharded(n_frames: int, run_shard, first_pose=None):
     """Runs `run_shard(frame_start, frame_stop, pair_offset) -> (pose[p,3,4], stats[p,8])` on this rank's frame range,
     gathers, and returns (relative poses [n_frames,3,4] incl. the first camera, global poses, stats) on every rank."""

@@ -598,16 +598,61 @@ def find_features_in_consecutive_frames_whole_movie(first_left_ex_cam_mat=M1, mo
     are read (a 3450-frame movie holds ~4.5 M Features; building them all up front took 8-12 s around a 17 ms device
     pass).  DataBase(...) recognises it and chains the tracks on the index arrays (types.ArrayDataBase)."""
     n = movie_len if movie_len is not None else min(MOVIE_LEN, len(DETECTIONS)) if hasattr(DETECTIONS, "__len__") else MOVIE_LEN
-    f0, f1 = pipeline.consecutive_pairs(n)
-    res, xy, _ = track_pairs_arrays(np.arange(n), f0, f1, seeds, host_kp=False)
-    _check_pairs(res)
-    flat, ptr = ops.compact_supporters(res.mask, res.stats[:, 0], res.tracked_kp)
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+        pose, stats, flat, ptr, xy = _whole_movie_sharded(n, seeds)
+    else:
+        f0, f1 = pipeline.consecutive_pairs(n)
+        res, xy, _ = track_pairs_arrays(np.arange(n), f0, f1, seeds, host_kp=False)
+        pose, stats = res.pose, res.stats
+        if not (stats[:, 5] & _lib.SLAM_PAIR_EMPTY).any():
+            flat, ptr = ops.compact_supporters(res.mask, stats[:, 0], res.tracked_kp)
+    if (stats[:, 5] & _lib.SLAM_PAIR_EMPTY).any():
+        raise ValueError("low >= high")          # np.random.randint(0, 0, 4) on an empty tracked set (:502)
     sup = [flat[ptr[p]:ptr[p + 1]] for p in range(n - 1)]
-    T = res.stats[:, 0].astype(np.int64)
-    percs = (100 * res.stats[:, 1].astype(np.int64) / T).tolist()          # :923, true division of Python ints
-    ok = res.ok
-    rel = [first_left_ex_cam_mat] + [res.pose[p] if ok[p] else None for p in range(n - 1)]
+    T = stats[:, 0].astype(np.int64)
+    percs = (100 * stats[:, 1].astype(np.int64) / T).tolist()              # :923, true division of Python ints
+    ok = (stats[:, 5] & _lib.SLAM_PAIR_OK) != 0
+    rel = [first_left_ex_cam_mat] + [pose[p] if ok[p] else None for p in range(n - 1)]
     return LazyPairFeatures(sup, xy, flat=(flat, ptr)), percs, convert_trans_from_rel_to_global(rel), rel
+
+
+def _whole_movie_sharded(n, seeds):
+    """The loop of :850 cut into one contiguous block of frame pairs per rank (one process per GPU, torch.distributed
+    initialised by the caller; README.md:58 of the reference: the pairs "can be done in parallel").  Rank r reads and
+    tracks only its frames (one halo frame); the per-pair seeds are rank 0's draws from ITS global random stream, so the
+    result is what one GPU returns for the same stream.  Exchanges: the seeds (broadcast), poses + counters, the
+    supporters' key-point rows and the frames' coordinates (all-gathers; RCCL over xGMI under the nccl backend).  Every
+    rank returns the whole movie's arrays."""
+    import torch.distributed as tdist
+    from . import dist as sdist
+    rank, world = tdist.get_rank(), tdist.get_world_size()
+    P = n - 1
+    if seeds is None and rank == 0:
+        seeds = np.random.randint(0, 2 ** 32, P, dtype=np.uint64)      # one draw from the global stream per pair
+    seeds = sdist.broadcast_array(seeds if rank == 0 else None, (P,), np.int64).astype(np.uint64)
+    a, b, fa, fb = sdist.shard_frames(n, rank, world)
+    xy_local = np.zeros((0, 2, 64, 2), np.float32)
+    pose_l, stats_l = np.zeros((0, 3, 4)), np.zeros((0, 8), np.int32)
+    flat_l, cnt_l = np.zeros((0, 4), np.int32), np.zeros(0, np.int64)
+    if b > a:
+        f0, f1 = pipeline.consecutive_pairs(fb - fa)
+        res, xy_local, _ = track_pairs_arrays(np.arange(fa, fb), f0, f1, seeds[a:b], host_kp=False)
+        pose_l, stats_l = res.pose, res.stats
+        if (stats_l[:, 5] & _lib.SLAM_PAIR_EMPTY).any():                # raised after the gather, on every rank alike
+            cnt_l = np.zeros(b - a, np.int64)
+        else:
+            flat_l, ptr_l = ops.compact_supporters(res.mask, stats_l[:, 0], res.tracked_kp)
+            cnt_l = np.diff(ptr_l)
+    pose, stats = sdist.gather_shard_results(pose_l, stats_l, P)
+    flat, ptr = sdist.gather_ragged_rows(flat_l, cnt_l, P)
+    n_max = sdist.max_over_ranks(xy_local.shape[2])                     # ranks pad their own frames; one width for the movie
+    if xy_local.shape[2] != n_max:
+        wide = np.zeros(xy_local.shape[:2] + (n_max, 2), np.float32)
+        wide[:, :, :xy_local.shape[2]] = xy_local
+        xy_local = wide
+    xy = sdist.gather_frames(xy_local, n)
+    return pose, stats, flat, ptr, xy
 
 
 def whole_movie_database(first_left_ex_cam_mat=M1, movie_len=None, seeds=None):

@@ -74,3 +74,52 @@ def test_two_rank_gather_equals_single_process():
         assert np.array_equal(glob, compose_global(want_rel))
         assert np.array_equal(stats[:, 0], want_stats[:, 0])
         assert set(stats[:, 1]) == {0, 19}                            # which rank's frame range produced each pair
+
+
+def _ragged_worker(rank, world, port, n_units, n_frames, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows, counts, frames = _ragged_case(n_units, n_frames)
+    ptr = np.concatenate([[0], np.cumsum(counts)])
+    a, b = sdist.block_range(n_units, rank, world)
+    got_rows, got_ptr = sdist.gather_ragged_rows(rows[ptr[a]:ptr[b]], counts[a:b], n_units)
+    pa, pb, fa, fb = sdist.shard_frames(n_frames, rank, world)
+    got_frames = sdist.gather_frames(frames[fa:fb], n_frames)
+    seeds = sdist.broadcast_array(np.arange(5) + 7 if rank == 0 else None, (5,), np.int64)
+    widest = sdist.max_over_ranks(64 * (rank + 1))
+    q.put((rank, got_rows, got_ptr, got_frames, seeds, widest))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _ragged_case(n_units, n_frames):
+    rng = np.random.default_rng(4)
+    counts = rng.integers(0, 9, n_units).astype(np.int64)
+    counts[min(3, n_units - 1)] = 0
+    rows = rng.integers(0, 2000, (int(counts.sum()), 4)).astype(np.int32)
+    frames = rng.random((n_frames, 2, 8, 2)).astype(np.float32)
+    return rows, counts, frames
+
+
+def test_ragged_rows_and_frames_gather_over_ranks():
+    """The exchanges of the sharded whole-movie driver (utills._whole_movie_sharded): supporters' key-point rows of
+    every pair (variable length, a pair without any, more ranks than pairs), the frames' coordinates (halo frames, the
+    movie's last frame), the seeds from rank 0, the common image width."""
+    for world, n_frames in ((2, 12), (3, 6), (3, 3)):
+        n_units = n_frames - 1
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, n_units, n_frames, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        rows, counts, frames = _ragged_case(n_units, n_frames)
+        for rank, g_rows, g_ptr, g_frames, seeds, widest in got:
+            assert g_rows.dtype == np.int32 and np.array_equal(g_rows, rows)
+            assert np.array_equal(g_ptr, np.concatenate([[0], np.cumsum(counts)]))
+            assert g_frames.dtype == np.float32 and np.array_equal(g_frames, frames)
+            assert list(seeds) == [7, 8, 9, 10, 11] and widest == 64 * world
