@@ -59,9 +59,13 @@ class KeyPoint:
 
 def keypoints_from_xy(xy) -> np.ndarray:
     """float[n, 2] -> object array of KeyPoint (what np.array(alg.detectAndCompute(...)[0]) yields, utills.py:54)."""
-    out = np.empty(len(xy), dtype=object)
-    for i, (x, y) in enumerate(xy):
-        out[i] = KeyPoint(x, y)
+    a = np.asarray(xy, dtype=np.float32).reshape(-1, 2).astype(np.float64)     # cv2 stores float32, returns Python floats
+    out = np.empty(len(a), dtype=object)
+    new = KeyPoint.__new__
+    for i, pt in enumerate(zip(a[:, 0].tolist(), a[:, 1].tolist())):           # one conversion for all, not two per point
+        k = new(KeyPoint)
+        k.pt = pt
+        out[i] = k
     return out
 
 
@@ -75,8 +79,12 @@ def keypoints_to_xy(kpts) -> np.ndarray:
 
 def dmatches_from_arrays(q, t, d) -> np.ndarray:
     out = np.empty(len(q), dtype=object)
-    for i in range(len(q)):
-        out[i] = DMatch(q[i], t[i], d[i])
+    new = DMatch.__new__
+    rows = zip(np.asarray(q, np.int64).tolist(), np.asarray(t, np.int64).tolist(), np.asarray(d, np.float64).tolist())
+    for i, (qi, ti, di) in enumerate(rows):
+        m = new(DMatch)
+        m.queryIdx, m.trainIdx, m.imgIdx, m.distance = qi, ti, 0, di
+        out[i] = m
     return out
 
 
