@@ -325,13 +325,14 @@ int launch_refit_t(const Mat33 &K, const double *d_X, const XY4 *d_xy1, const in
     int cap = std::min(seg_stride, n_seg <= 256 ? 4096 : SLAM_REFIT_CAP);
     size_t lds_bytes = (size_t)cap * per;
     if (lds_bytes > 64 * 1024) {
-        static bool raised = false, raise_ok = false;
-        if (!raised) {
-            raise_ok = hipFuncSetAttribute((const void *)refit_kernel<XY4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024) == hipSuccess;
+        // once per process and kernel instantiation (one process per GPU); a function-local static is initialised
+        // under the runtime's guard, so concurrent first calls from several host threads are safe
+        static const bool raise_ok = [] {
+            const bool ok = hipFuncSetAttribute((const void *)refit_kernel<XY4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                160 * 1024) == hipSuccess;
             (void)hipGetLastError();
-            raised = true;
-        }
+            return ok;
+        }();
         if (!raise_ok) {
             cap = (int)(64 * 1024 / per);
             lds_bytes = (size_t)cap * per;
