@@ -649,10 +649,10 @@ def run_loops(args, rk: Rank):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
-    if args.gpus > 1 and "RANK" not in os.environ:
-        return self_launch(args, argv)                                     # before anything touches the GPU
     if args.config != "trajectory" and args.gpus != 1:
         raise SystemExit("--config stress / loops are one-GPU configurations")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(args, argv)                                     # before anything touches the GPU
     if not args.frames:
         args.frames = 31 if args.config == "stress" else 3450
     if not args.features:
