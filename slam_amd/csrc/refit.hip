@@ -1,5 +1,5 @@
 // PnP refit on the supporters: Levenberg-Marquardt on the left-image reprojection error, one wavefront per
-// frame pair.
+// frame pair (four when the launch is too small to fill the chip).
 //
 // Replaces extra_refine -> pnp(world[mask], left1[mask], K, cv2.SOLVEPNP_ITERATIVE) (utils/utills.py:548-571,
 // :585-596).  cv2's ITERATIVE solver is a DLT initialisation followed by Levenberg-Marquardt (CvLevMarq, at
@@ -10,6 +10,7 @@
 // (rvec, tvec) parameters.  Same minimiser, hence the 1e-5 relative pose tolerance of the parity tests;
 // OpenCV itself is absent, so this is "parity unpinned" against cv2 and pinned against oracle/slam_oracle.py.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "jacobi.h"   // rcp_nr
@@ -112,35 +113,63 @@ constexpr int MAX_EVAL = 60;
 #define SLAM_REFIT_STEP2 1e-18
 #endif
 
+// Wavefronts per pair (RW).  A pair's solve is one long dependent chain (passes over the supporters, 27 butterfly
+// reductions, a serial 6x6 Cholesky, the pose update): ~100 us whatever the launch.  A whole shard hides that behind
+// other pairs (three per CU by LDS, 4.5 rounds: 0.41 ms) and splitting a pair over four wavefronts only adds
+// instructions there (0.47 ms).  A launch that does not fill the chip -- a loop-closure call with a handful of
+// candidates, a rank's share of a strongly scaled movie, the 8k-feature configuration's 30 pairs -- is all latency:
+// then the passes over the points are split over four wavefronts, the scalar part (reduced sums -> step -> new pose)
+// being computed redundantly by every thread from the same bits, so control flow stays uniform over the workgroup.
+//
 // LDS: the supporters of the pair, compacted once (x, y, z as doubles + the left observation in its own type: 32 bytes per
 // supporter for float32 key-point rows), when there are at most `cap` of them; every Levenberg-Marquardt pass then reads them from LDS with all
 // lanes busy.  (Round 1 re-read the tracked points from global memory in every pass, masked: ~15 passes x 48 KB per
 // pair = 1.78 GB of fabric reads per launch for 0.2 GB of data.)  A pair with more supporters than `cap` walks global
 // memory as before.
-template <typename XY4>
-__global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, const XY4 *xy1, const int *count,
-                                                   int seg_stride, const unsigned long long *mask_words,
-                                                   const double *pose0, double *pose_out, uint8_t *status, int cap) {
+template <typename XY4, int RW>
+__global__ __launch_bounds__(RW * 64) void refit_kernel(Mat33 K, const double *X, const XY4 *xy1, const int *count,
+                                                        int seg_stride, const unsigned long long *mask_words,
+                                                        const double *pose0, double *pose_out, uint8_t *status, int cap) {
+    constexpr int RT = RW * 64;
     extern __shared__ double lds[];
+    __shared__ double red[RW][28];           // per-wavefront partial sums of one reduction round
+    __shared__ int wave_supp[RW];
     using UV = decltype(XY4::x);             // observations keep the caller's type: float32 key-point rows or float64
     double *sx = lds, *sy = lds + cap, *sz = lds + 2 * cap;
     UV *su = (UV *)(lds + 3 * cap), *sv = su + cap;
-    const int seg = blockIdx.x, lane = threadIdx.x;
+    const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = count[seg];
     const int words = seg_stride / 64;
+    const int n_words = (n + 63) / 64;
     const unsigned long long *mw = mask_words + (size_t)seg * words;
     const double *Xs = X + (size_t)seg * seg_stride * 3;
     const XY4 *obs = xy1 + (size_t)seg * seg_stride;
     const double fx = K.m[0], fy = K.m[4], cx = K.m[2], cy = K.m[5];
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
 
-    int supp = 0;
-    for (int w = lane; w * 64 < n; w += 64) supp += __popcll(mw[w]);
+    // the 64-point mask words are dealt round-robin to the wavefronts: word j belongs to wavefront j % RW
+    int mine = 0;
+    for (int j = wave + RW * lane; j < n_words; j += RW * 64) {
+        unsigned long long m = mw[j];
+        if (j == n_words - 1 && (n & 63)) m &= (1ull << (n & 63)) - 1ull;
+        mine += __popcll(m);
+    }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) supp += __shfl_xor(supp, m);
+    for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m);
+    int supp = mine, my_offset = 0;
+    if (RW > 1) {
+        if (lane == 0) wave_supp[wave] = mine;
+        __syncthreads();
+        supp = 0;
+#pragma unroll
+        for (int w = 0; w < RW; ++w) {
+            if (w < wave) my_offset += wave_supp[w];
+            supp += wave_supp[w];
+        }
+    }
     if (supp < 6) {   // utills.py:558-559: pose None
-        if (lane < 12) pose_out[(size_t)seg * 12 + lane] = qnan;
-        if (lane == 0) status[seg] = 0;
+        if (tid < 12) pose_out[(size_t)seg * 12 + tid] = qnan;
+        if (tid == 0) status[seg] = 0;
         return;
     }
 
@@ -153,18 +182,19 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
     }
 
     constexpr int UN = 4;
-    const bool in_lds = supp <= cap;          // wave-uniform
+    const bool in_lds = supp <= cap;          // uniform over the workgroup
     if (in_lds) {
-        // ordered compaction, four wave-steps of loads in flight at a time
-        int base_out = 0;
-        for (int base = 0; base < n; base += 64 * UN) {
+        // ordered compaction inside a wavefront's words (UN words of loads in flight at a time); wavefront w's supporters
+        // follow those of the wavefronts before it.  Any fixed order will do: it only sets the order of the sums.
+        int base_out = my_offset;
+        for (int j0 = wave; j0 < n_words; j0 += RW * UN) {
             double px[UN], py[UN], pz[UN];
             UV ou[UN], ov[UN];
             bool ok[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int i = base + u * 64 + lane;
-                ok[u] = i < n && ((mw[i >> 6] >> (i & 63)) & 1ull);
+                const int j = j0 + u * RW, i = j * 64 + lane;
+                ok[u] = j < n_words && i < n && ((mw[j < n_words ? j : 0] >> lane) & 1ull);
                 if (ok[u]) {
                     px[u] = Xs[i * 3], py[u] = Xs[i * 3 + 1], pz[u] = Xs[i * 3 + 2];
                     const XY4 o = obs[i];
@@ -185,20 +215,20 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
         __syncthreads();
     }
 
-    // body(x, y, z, u, v) for every supporter; every lane adds its points in a fixed order, so a call's sums are
+    // body(x, y, z, u, v) for every supporter; every thread adds its points in a fixed order, so a call's sums are
     // reproducible bit for bit
     auto for_supporters = [&](auto body) {
         if (in_lds) {
-            for (int i = lane; i < supp; i += 64) body(sx[i], sy[i], sz[i], (double)su[i], (double)sv[i]);
+            for (int i = tid; i < supp; i += RT) body(sx[i], sy[i], sz[i], (double)su[i], (double)sv[i]);
         } else {
-            // walk the tracked points four wave-steps (256 points) at a time with the loads of all four issued before
-            // the arithmetic: one wave per pair is latency bound
-            for (int base = 0; base < n; base += 64 * UN) {
+            // walk the tracked points UN workgroup-steps at a time with the loads of all of them issued before the
+            // arithmetic: this path is latency bound
+            for (int base = 0; base < n; base += RT * UN) {
                 double px[UN], py[UN], pz[UN], ou[UN], ov[UN];
                 bool ok[UN];
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
-                    const int i = base + u * 64 + lane;
+                    const int i = base + u * RT + tid;
                     ok[u] = i < n && ((mw[i >> 6] >> (i & 63)) & 1ull);
                     if (ok[u]) {
                         px[u] = Xs[i * 3], py[u] = Xs[i * 3 + 1], pz[u] = Xs[i * 3 + 2];
@@ -213,17 +243,40 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
         }
     };
 
+    // v[0..N) summed over the workgroup: butterfly inside each wavefront, then the RW partial sums through LDS, added
+    // in wavefront order by every thread (same bits everywhere)
+    auto block_sum = [&](auto &v, auto n_vals) {
+        constexpr int N = decltype(n_vals)::value;
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+        if (RW == 1) return;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) red[wave][k] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            double t = red[0][k];
+#pragma unroll
+            for (int w = 1; w < RW; ++w) t += red[w][k];
+            v[k] = t;
+        }
+        __syncthreads();               // red is free for the next round
+    };
+
     auto cost_of = [&](const Pose &Q) {
-        double c = 0;
+        double c[1] = {0};
         for_supporters([&](double x, double y, double z, double ou, double ov) {
             const double xc = Q.R[0][0] * x + Q.R[0][1] * y + Q.R[0][2] * z + Q.t[0];
             const double yc = Q.R[1][0] * x + Q.R[1][1] * y + Q.R[1][2] * z + Q.t[1];
             const double zc = Q.R[2][0] * x + Q.R[2][1] * y + Q.R[2][2] * z + Q.t[2];
             const double iz = rcp_nr(zc);      // refined hardware reciprocal: the minimiser does not depend on the last ulp
             const double ru = fx * xc * iz + cx - ou, rv = fy * yc * iz + cy - ov;
-            c += ru * ru + rv * rv;
+            c[0] += ru * ru + rv * rv;
         });
-        return wave_sum(c);
+        block_sum(c, std::integral_constant<int, 1>{});
+        return c[0];
     };
 
     double lambda = 1e-3;
@@ -231,12 +284,10 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
     int evals = 0;
     bool done = false;
     while (!done && evals < MAX_EVAL) {
-        // normal equations at P
-        double H[21], g[6];
+        // normal equations at P: 21 entries of J^T J, then the 6 of J^T r
+        double Hg[27];
 #pragma unroll
-        for (int k = 0; k < 21; ++k) H[k] = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) g[k] = 0;
+        for (int k = 0; k < 27; ++k) Hg[k] = 0;
         for_supporters([&](double x, double y, double z, double ou, double ov) {
             const double xc = P.R[0][0] * x + P.R[0][1] * y + P.R[0][2] * z + P.t[0];
             const double yc = P.R[1][0] * x + P.R[1][1] * y + P.R[1][2] * z + P.t[1];
@@ -252,14 +303,11 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
 #pragma unroll
-                for (int b = a; b < 6; ++b) H[k++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
-                g[a] += Ju[a] * ru + Jv[a] * rv;
+                for (int b = a; b < 6; ++b) Hg[k++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+                Hg[21 + a] += Ju[a] * ru + Jv[a] * rv;
             }
         });
-#pragma unroll
-        for (int k = 0; k < 21; ++k) H[k] = wave_sum(H[k]);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) g[k] = wave_sum(g[k]);
+        block_sum(Hg, std::integral_constant<int, 27>{});
 
         bool stepped = false;
         while (!stepped && evals < MAX_EVAL) {
@@ -269,11 +317,11 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
             for (int a = 0; a < 6; ++a) {
 #pragma unroll
                 for (int b = a; b < 6; ++b) {
-                    A[a][b] = H[k];
-                    A[b][a] = H[k];
+                    A[a][b] = Hg[k];
+                    A[b][a] = Hg[k];
                     ++k;
                 }
-                rhs[a] = -g[a];
+                rhs[a] = -Hg[21 + a];
             }
 #pragma unroll
             for (int a = 0; a < 6; ++a) A[a][a] *= 1.0 + lambda;   // Marquardt scaling, as CvLevMarq
@@ -302,7 +350,7 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
             }
         }
     }
-    if (lane == 0) {
+    if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -318,30 +366,46 @@ __global__ __launch_bounds__(64) void refit_kernel(Mat33 K, const double *X, con
 #ifndef SLAM_REFIT_CAP
 #define SLAM_REFIT_CAP 1536
 #endif
-template <typename XY4>
-int launch_refit_t(const Mat33 &K, const double *d_X, const XY4 *d_xy1, const int32_t *d_count, int n_seg, int seg_stride,
-                   const uint64_t *d_mask_words, const double *d_pose0, double *d_pose, uint8_t *d_status, hipStream_t st) {
+// launches smaller than this many pairs run four wavefronts per pair (see RW above): below it the 256 CUs are not
+// filled by one-wavefront workgroups three to a CU
+#ifndef SLAM_REFIT_WIDE_BELOW
+#define SLAM_REFIT_WIDE_BELOW 768
+#endif
+
+template <typename XY4, int RW>
+int launch_refit_rw(const Mat33 &K, const double *d_X, const XY4 *d_xy1, const int32_t *d_count, int n_seg, int seg_stride,
+                    const uint64_t *d_mask_words, const double *d_pose0, double *d_pose, uint8_t *d_status, hipStream_t st) {
     const size_t per = 24 + 2 * sizeof(decltype(XY4::x));       // LDS bytes per supporter
+    constexpr size_t LDS_DEFAULT = 60 * 1024, LDS_RAISED = 158 * 1024;   // dynamic part; the kernel's static arrays take < 1 KB of the 64 / 160 KB
     int cap = std::min(seg_stride, n_seg <= 256 ? 4096 : SLAM_REFIT_CAP);
+    cap = std::min(cap, (int)(LDS_RAISED / per));
     size_t lds_bytes = (size_t)cap * per;
-    if (lds_bytes > 64 * 1024) {
+    if (lds_bytes > LDS_DEFAULT) {
         // once per process and kernel instantiation (one process per GPU); a function-local static is initialised
         // under the runtime's guard, so concurrent first calls from several host threads are safe
         static const bool raise_ok = [] {
-            const bool ok = hipFuncSetAttribute((const void *)refit_kernel<XY4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                160 * 1024) == hipSuccess;
+            const bool ok = hipFuncSetAttribute((const void *)refit_kernel<XY4, RW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)LDS_RAISED) == hipSuccess;
             (void)hipGetLastError();
             return ok;
         }();
         if (!raise_ok) {
-            cap = (int)(64 * 1024 / per);
+            cap = (int)(LDS_DEFAULT / per);
             lds_bytes = (size_t)cap * per;
         }
     }
-    hipLaunchKernelGGL(refit_kernel<XY4>, dim3(n_seg), dim3(64), lds_bytes, st, K, d_X, d_xy1, d_count, seg_stride,
+    hipLaunchKernelGGL((refit_kernel<XY4, RW>), dim3(n_seg), dim3(RW * 64), lds_bytes, st, K, d_X, d_xy1, d_count, seg_stride,
                        (const unsigned long long *)d_mask_words, d_pose0, d_pose, d_status, cap);
     SLAM_HIP_CHECK(hipGetLastError());
     return SLAM_OK;
+}
+
+template <typename XY4>
+int launch_refit_t(const Mat33 &K, const double *d_X, const XY4 *d_xy1, const int32_t *d_count, int n_seg, int seg_stride,
+                   const uint64_t *d_mask_words, const double *d_pose0, double *d_pose, uint8_t *d_status, hipStream_t st) {
+    if (n_seg < SLAM_REFIT_WIDE_BELOW)
+        return launch_refit_rw<XY4, 4>(K, d_X, d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status, st);
+    return launch_refit_rw<XY4, 1>(K, d_X, d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status, st);
 }
 
 }  // namespace
