@@ -80,3 +80,38 @@ def test_triangulation_inverts_projection():
     pl = X @ P[:, :3].T + P[:, 3]; pr = X @ Q[:, :3].T + Q[:, 3]
     got = ops.triangulate_f64(P, Q, dev(pl[:, :2] / pl[:, 2:]), dev(pr[:, :2] / pr[:, 2:])).cpu().numpy()
     assert (np.linalg.norm(got - X, axis=1) / np.linalg.norm(X, axis=1)).max() < 1e-8
+
+
+@pytest.mark.parametrize("case", ["lds_raised_f64", "beyond_lds_f64", "beyond_lds_f32", "many_pairs_one_wavefront_each"])
+def test_refit_kernel_variants_reach_the_same_minimiser(case):
+    """The refit has two shapes (four wavefronts per pair for small launches, one for launches that fill the chip) and
+    two homes for the supporters (LDS up to a cap that depends on the observation type; beyond it, global memory).  All
+    of them must end at the same stationary point: checked against each other through a float64 numpy Gauss-Newton
+    polish of the result, which must not move it."""
+    rng = np.random.default_rng(77)
+    n, stride, n_seg, dtype = {"lds_raised_f64": (3000, 4160, 3, np.float64), "beyond_lds_f64": (4100, 4160, 3, np.float64),
+                               "beyond_lds_f32": (4150, 4160, 2, np.float32),
+                               "many_pairs_one_wavefront_each": (300, 320, 800, np.float32)}[case]
+    T, X, uv_exact = _scene(rng, n)
+    uv = (uv_exact + rng.normal(0, 0.5, (n, 2))).astype(dtype)
+    start = np.hstack([Rotation.from_rotvec(rng.normal(0, 2e-3, 3)).as_matrix() @ T[:, :3], T[:, 3:] + rng.normal(0, 0.02, (3, 1))])
+    Xs = np.zeros((n_seg, stride, 3)); Xs[:, :n] = X
+    xy1 = np.zeros((n_seg, stride, 4), dtype); xy1[:, :n, :2] = uv
+    sel = np.ones(n, bool); sel[::17] = False
+    words = ops.bool_to_mask_words(np.repeat(sel[None], n_seg, 0), stride)
+    pose, status = ops.refit_pnp(K, dev(Xs), dev(xy1), dev(np.full(n_seg, n, np.int32)), dev(words), dev(np.repeat(start[None], n_seg, 0)))
+    pose, status = pose.cpu().numpy(), status.cpu().numpy()
+    assert status.all() and np.abs(pose - pose[0]).max() == 0.0          # every segment: same data, same bits
+    got, obs = pose[0], uv.astype(np.float64)[sel]
+
+    def residual(d):
+        R = Rotation.from_rotvec(d[:3]).as_matrix() @ got[:, :3]
+        P = K @ np.hstack([R, (got[:, 3] + d[3:]).reshape(3, 1)])
+        h = X[sel] @ P[:, :3].T + P[:, 3]
+        return (h[:, :2] / h[:, 2:] - obs).reshape(-1)
+
+    r0 = residual(np.zeros(6))
+    J = np.stack([(residual(np.eye(6)[a] * 1e-6) - residual(-np.eye(6)[a] * 1e-6)) / 2e-6 for a in range(6)], 1)
+    step = np.linalg.lstsq(J, -r0, rcond=None)[0]                         # the Gauss-Newton step from the kernel's answer
+    assert np.abs(step).max() < 1e-8, step
+    assert np.linalg.norm(got - T) / np.linalg.norm(T) < 2e-3
