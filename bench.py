@@ -355,49 +355,66 @@ def run_trajectory(args, rk: Rank):
 def pcie_inclusive(args, leg):
     """The same step with the shard's detections starting in pinned HOST memory (slam_amd/ingest.py): the H2D copy
     alone, the step with the copy in front of it, and the step with the next shard's copy overlapped (double
-    buffered).  Reported beside `value`, never as it: `value` is quoted with detections resident in HBM."""
+    buffered) -- in the padded hand-over format and in the dense wire format (61-byte rows, no empty rows; unpacked on
+    the device by slam_unpack_detections).  Reported beside `value`, never as it: `value` is quoted with detections
+    resident in HBM."""
     import torch
     from slam_amd import ingest
     desc, xy, count, trk, f0, f1, seeds = (leg[k] for k in ("desc", "xy", "count", "trk", "f0", "f1", "seeds"))
     F, n_max = len(count), desc.shape[2]
+    P = len(f0)
+    n = max(2, min(args.steps, 4))
+
+    def measure(st):
+        def run(k):
+            d = st.device(k)
+            trk.run(*d, f0, f1, seeds, unpack_mask=False)
+            st.release(k)
+
+        st.upload(0); st.upload(1); torch.cuda.synchronize()                  # first touch of the device slots
+        t0 = time.perf_counter()
+        for k in range(n):
+            st.upload(k)
+        torch.cuda.synchronize()
+        h2d_ms = 1e3 * (time.perf_counter() - t0) / n
+        t0 = time.perf_counter()
+        for k in range(n):                                                    # copy, then compute, nothing overlapped
+            st.upload(k)
+            torch.cuda.synchronize()
+            run(k)
+        torch.cuda.synchronize()
+        serial_ms = 1e3 * (time.perf_counter() - t0) / n
+        st.upload(0)
+        torch.cuda.synchronize()                                              # pipeline filled: steady state of a stream of shards
+        t0 = time.perf_counter()
+        for k in range(n):                                                    # shard k+1 uploads while shard k is tracked
+            st.upload(k + 1)
+            run(k)
+        torch.cuda.synchronize()
+        overlap_ms = 1e3 * (time.perf_counter() - t0) / n
+        gb = st.bytes_per_shard() / 1e9
+        return {"h2d_ms_per_shard": round(h2d_ms, 3), "h2d_GBps": round(gb / (h2d_ms * 1e-3), 2), "shard_GB": round(gb, 3),
+                "serial_ms_per_step": round(serial_ms, 3), "serial_frame_pairs_per_s": round(P / (serial_ms * 1e-3), 1),
+                "overlapped_ms_per_step": round(overlap_ms, 3),
+                "overlapped_frame_pairs_per_s": round(P / (overlap_ms * 1e-3), 1), "steps": n}
+
     st = ingest.ShardStager(F, n_max)
     for k in range(2):
         s = st.host_slot(k)
         s.desc[:], s.xy[:], s.count[:] = desc, xy, count
-    P = len(f0)
-    n = max(2, min(args.steps, 4))
-
-    def run(k):
-        d = st.device(k)
-        trk.run(*d, f0, f1, seeds, unpack_mask=False)
-        st.release(k)
-
-    st.upload(0); st.upload(1); torch.cuda.synchronize()                  # first touch of the device slots
-    t0 = time.perf_counter()
-    for k in range(n):
-        st.upload(k)
-    torch.cuda.synchronize()
-    h2d_ms = 1e3 * (time.perf_counter() - t0) / n
-    t0 = time.perf_counter()
-    for k in range(n):                                                    # copy, then compute, nothing overlapped
-        st.upload(k)
-        torch.cuda.synchronize()
-        run(k)
-    torch.cuda.synchronize()
-    serial_ms = 1e3 * (time.perf_counter() - t0) / n
-    st.upload(0)
-    torch.cuda.synchronize()                                              # pipeline filled: steady state of a stream of shards
-    t0 = time.perf_counter()
-    for k in range(n):                                                    # shard k+1 uploads while shard k is tracked
-        st.upload(k + 1)
-        run(k)
-    torch.cuda.synchronize()
-    overlap_ms = 1e3 * (time.perf_counter() - t0) / n
-    gb = st.bytes_per_shard() / 1e9
-    return {"h2d_ms_per_shard": round(h2d_ms, 3), "h2d_GBps": round(gb / (h2d_ms * 1e-3), 2), "shard_GB": round(gb, 3),
-            "serial_ms_per_step": round(serial_ms, 3), "serial_frame_pairs_per_s": round(P / (serial_ms * 1e-3), 1),
-            "overlapped_ms_per_step": round(overlap_ms, 3),
-            "overlapped_frame_pairs_per_s": round(P / (overlap_ms * 1e-3), 1), "steps": n}
+    out = measure(st)
+    del st
+    torch.cuda.empty_cache()
+    dst = ingest.DenseShardStager(F, n_max, width=61)
+    for k in range(2):
+        s = dst.host_slot(k)
+        s.reset()
+        for j in range(F):
+            for side in range(2):
+                c = int(count[j, side])
+                s.put(j, side, xy[j, side, :c], desc[j, side, :c, :61])
+    out["dense_wire_format"] = measure(dst)
+    return out
 
 
 def dropin_whole_movie(args, leg):

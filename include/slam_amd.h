@@ -199,6 +199,23 @@ int slam_refit_pnp(const double *h_K, const double *d_X, const void *d_xy1, int 
                    uint8_t *d_status, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Ingest: dense wire format -> padded device layout.  No counterpart in the reference, which hands every image's
+ * detections over as Python objects (utils/utills.py:46-54, cv2 detectAndCompute -> key-point list + descriptor ndarray);
+ * this is how a shard of them reaches the layout every entry point above reads (d_desc [n_img][n_max][64],
+ * d_xy [n_img][n_max][2]) with 8 % fewer bytes over PCIe than uploading that layout itself.
+ *   d_dense_desc [n_rows_total][desc_width]  descriptor rows at their own width (61 for AKAZE MLDB), any image order;
+ *                                            4-byte aligned
+ *   d_dense_xy   [n_rows_total][2]           KeyPoint.pt of the same rows
+ *   d_row_ptr    [n_img] int64               first dense row of image k;  d_count [n_img]: its rows
+ * Every byte of d_desc / d_xy is written: rows past an image's count and bytes past desc_width are zero, so the result
+ * equals a padded upload.  d_count_out [n_img]: the counts clamped to [0, n_max]; an image whose row range does not lie
+ * inside the dense arrays is unpacked as empty.
+ */
+int slam_unpack_detections(const uint8_t *d_dense_desc, const float *d_dense_xy, const int64_t *d_row_ptr,
+                           const int32_t *d_count, int n_img, int n_max, int desc_width, int64_t n_rows_total,
+                           uint8_t *d_desc, float *d_xy, int32_t *d_count_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Trajectory composition (host).  Replaces convert_trans_from_rel_to_global (utils/utills.py:749-757):
  * global[i] = rel[i] @ [global[i-1]; 0 0 0 1], started from rel[0] (so rel[0] is applied twice, as in the
  * reference, which is harmless for [I|0]).  h_rel, h_global: [n][12] row-major 3x4.

@@ -74,6 +74,8 @@ SIGNATURES = {
     "slam_refit_pnp": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p]),
     "slam_compose_global": (c_int, [c_void_p, c_int, c_void_p]),
+    "slam_unpack_detections": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_int64, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
     "slam_chain_tracks": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "slam_track_device_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_void_p]),

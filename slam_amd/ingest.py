@@ -13,6 +13,10 @@ asynchronous copy per array on a dedicated HIP stream.  Two host slots and two d
 detected / packed / uploaded while shard s is being tracked; consecutive shards share one halo frame so that every
 consecutive frame pair belongs to exactly one shard (same partition as slam_amd/dist.py).
 
+DENSE variant (DenseShardStager): the same shard as descriptor rows at their own width (61 bytes for AKAZE), their
+coordinates and a row pointer per image -- 8 % fewer bytes over PCIe, which is what bounds a stream of shards -- that
+libslam_amd's slam_unpack_detections expands into the padded device layout (bit-identical to a padded upload).
+
 Nothing here computes on the detections: the arithmetic stays in libslam_amd.  torch is used for pinned memory,
 streams and events only.
 """
@@ -149,6 +153,129 @@ class ShardStager:
         self._uploaded[k % self.n_slots].synchronize()
 
 
+class DenseHostSlot:
+    """Pinned host arrays of one dense shard: desc uint8[capacity, width], xy float32[capacity, 2], count int32[F, 2],
+    row_ptr int64[F, 2].  Detector workers call put(frame, side, pts, dsc) from any thread, in any order: an image gets
+    the next free run of rows."""
+
+    def __init__(self, desc, xy, count, row_ptr):
+        self.desc, self.xy, self.count, self.row_ptr = desc, xy, count, row_ptr
+        self.rows_used = 0
+        self._lock = threading.Lock()
+
+    def reset(self) -> None:
+        self.rows_used = 0
+        self.count[:] = 0
+        self.row_ptr[:] = 0
+
+    def put(self, frame: int, side: int, pts, dsc) -> int:
+        n = 0 if dsc is None else len(dsc)
+        with self._lock:
+            a = self.rows_used
+            if a + n > len(self.desc):
+                raise ValueError("dense slot is full")
+            self.rows_used = a + n
+        if n:
+            d = np.asarray(dsc, dtype=np.uint8)
+            w = self.desc.shape[1]
+            if d.ndim != 2 or d.shape[1] > w:
+                if d.ndim == 2 and not d[:, w:].any():
+                    d = d[:, :w]                                  # zero padding beyond the slot's width carries nothing
+                else:
+                    raise ValueError(f"descriptors must be uint8[n, <={w}]")
+            self.desc[a:a + n, :d.shape[1]] = d
+            self.desc[a:a + n, d.shape[1]:] = 0
+            self.xy[a:a + n] = np.asarray(pts, dtype=np.float32).reshape(n, 2)
+        self.count[frame, side], self.row_ptr[frame, side] = n, a
+        return n
+
+
+class DenseShardStager(ShardStager):
+    """ShardStager whose host slots and uploads are dense (see the module docstring); device(k) unpacks into the same
+    padded device tensors ShardStager hands out.
+
+        st = DenseShardStager(F, n_max, width=61)
+        slot = st.host_slot(k); slot.reset(); slot.put(frame, side, pts, dsc) ...
+        st.upload(k, n_frames); desc, xy, count = st.device(k); ...; st.release(k)"""
+
+    def __init__(self, n_frames: int, n_max: int, width: int = 61, n_slots: int = 2, piece_bytes: int = PIECE_BYTES):
+        if n_max % 64:
+            raise ValueError("n_max must be a multiple of 64")
+        if not 1 <= width <= ROW_BYTES:
+            raise ValueError("descriptor width must be 1 .. 64 bytes")
+        self.n_frames, self.n_max, self.n_slots, self.width = n_frames, n_max, n_slots, width
+        self.piece_bytes = int(piece_bytes)
+        self.dev = ops.device()
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        F, cap = n_frames, 2 * n_frames * n_max
+        self._h, self._dd, self._d, self._views = [], [], [], []
+        for _ in range(n_slots):
+            h = (torch.zeros((cap, width), dtype=torch.uint8).pin_memory(), torch.zeros((cap, 2), dtype=torch.float32).pin_memory(),
+                 torch.zeros((2 * F,), dtype=torch.int32).pin_memory(), torch.zeros((2 * F,), dtype=torch.int64).pin_memory())
+            self._h.append(h)
+            self._dd.append(tuple(torch.empty(t.shape, dtype=t.dtype, device=self.dev) for t in h))      # dense, on the device
+            self._d.append((torch.empty((2 * F, n_max, ROW_BYTES), dtype=torch.uint8, device=self.dev),
+                            torch.empty((2 * F, n_max, 2), dtype=torch.float32, device=self.dev),
+                            torch.empty((2 * F,), dtype=torch.int32, device=self.dev)))
+            self._views.append(DenseHostSlot(h[0].numpy(), h[1].numpy(), h[2].numpy().reshape(F, 2), h[3].numpy().reshape(F, 2)))
+        self._uploaded = [torch.cuda.Event() for _ in range(n_slots)]
+        self._released = [None] * n_slots
+        self._frames = [0] * n_slots
+        self._rows = [0] * n_slots
+
+    def bytes_per_shard(self, n_frames: int | None = None, k: int = 0) -> int:
+        F = self.n_frames if n_frames is None else n_frames
+        return self._views[k % self.n_slots].rows_used * (self.width + 8) + 2 * F * 12
+
+    def upload(self, k: int, n_frames: int | None = None) -> None:
+        k %= self.n_slots
+        F = self.n_frames if n_frames is None else int(n_frames)
+        if not 0 < F <= self.n_frames:
+            raise ValueError("shard larger than the stager's slots")
+        rows = self._views[k].rows_used
+        with torch.cuda.stream(self.copy_stream):
+            if self._released[k] is not None:
+                self.copy_stream.wait_event(self._released[k])     # compute still reading the device slot
+            for h, d, n in zip(self._h[k], self._dd[k], (rows, rows, 2 * F, 2 * F)):
+                step = max(1, self.piece_bytes // max(1, h[0].numel() * h.element_size()))
+                for a in range(0, n, step):
+                    b = min(n, a + step)
+                    d[a:b].copy_(h[a:b], non_blocking=True)
+            self._uploaded[k].record(self.copy_stream)
+        self._frames[k], self._rows[k] = F, rows
+
+    def device(self, k: int):
+        k %= self.n_slots
+        F = self._frames[k]
+        if F == 0:
+            raise RuntimeError("slot was never uploaded")
+        torch.cuda.current_stream(self.dev).wait_event(self._uploaded[k])
+        dd, d = self._dd[k], self._d[k]
+        from . import _lib
+        _lib.check(_lib.lib().slam_unpack_detections(dd[0].data_ptr(), dd[1].data_ptr(), dd[3].data_ptr(), dd[2].data_ptr(), 2 * F,
+                                                     self.n_max, self.width, self._rows[k], d[0].data_ptr(), d[1].data_ptr(),
+                                                     d[2].data_ptr(), ops._stream()))
+        return d[0][:2 * F], d[1][:2 * F], d[2][:2 * F]
+
+
+def fill_dense_slot(slot: DenseHostSlot, source, first: int, last: int, workers: int = 8) -> None:
+    """fill_slot for a dense slot: frames [first, last) of a detection source, one frame per task, rows allocated as the
+    images arrive."""
+    slot.reset()
+
+    def one(j):
+        pl, dl, pr, dr = source.get(first + j)
+        slot.put(j, 0, pl, dl)
+        slot.put(j, 1, pr, dr)
+    n = last - first
+    if workers <= 1 or n < 4:
+        for j in range(n):
+            one(j)
+    else:
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(one, range(n)))
+
+
 class CachedDetections:
     """Detection source that remembers the last `capacity` frames.
 
@@ -220,14 +347,16 @@ def fill_slot(slot: HostSlot, source, first: int, last: int, workers: int = 8) -
 
 
 def track_movie_streamed(source, n_frames_total: int, n_max: int, frames_per_shard: int, cfg: HotPathConfig | None = None,
-                         seed_of_pair=None, n_chunks: int = 2, workers: int = 8):
+                         seed_of_pair=None, n_chunks: int = 2, workers: int = 8, dense_width: int | None = None):
     """Whole-movie relative poses (find_features_in_consecutive_frames_whole_movie, utils/utills.py:834-873) for a movie
     that is detected shard by shard: while shard s is tracked on the GPU the host packs and uploads shard s+1.
     seed_of_pair(first_pair, n) -> uint32[n] gives np.random.seed values per pair (default 1000 + pair index).
+    dense_width: descriptor bytes per row (61 for AKAZE) to send the shards in the dense wire format.
     Returns (pose float64[n-1,3,4], stats int32[n-1,8])."""
     ranges = shard_ranges(n_frames_total, frames_per_shard)
     Fm = max(b - a for a, b in ranges)
-    st = ShardStager(Fm, n_max)
+    st = DenseShardStager(Fm, n_max, dense_width) if dense_width else ShardStager(Fm, n_max)
+    fill = fill_dense_slot if dense_width else fill_slot
     trk = pipeline.ShardTracker(Fm, Fm - 1, n_max, cfg, n_chunks=n_chunks)
     if seed_of_pair is None:
         seed_of_pair = lambda first, n: 1000 + first + np.arange(n)
@@ -237,7 +366,7 @@ def track_movie_streamed(source, n_frames_total: int, n_max: int, frames_per_sha
         def stage(s):
             a, b = ranges[s]
             st.host_ready(s)
-            fill_slot(st.host_slot(s), source, a, b, workers)
+            fill(st.host_slot(s), source, a, b, workers)
             return s
         pending = feeder.submit(stage, 0)
         for s, (a, b) in enumerate(ranges):

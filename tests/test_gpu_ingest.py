@@ -63,3 +63,68 @@ def test_stager_slots_round_trip_and_reject_oversize():
     with pytest.raises(ValueError):
         st.upload(0, 5)
     assert st.bytes_per_shard() == 2 * 4 * 128 * 72 + 32
+
+
+@pytest.mark.parametrize("width", [61, 32, 64])
+def test_dense_wire_format_unpacks_to_the_padded_layout(width):
+    """DenseShardStager: images put in any order, empty and full ones, several widths; after upload + unpack the
+    device tensors equal the padded layout byte for byte (zeros past every count and past the descriptor width), also
+    when a slot is reused for a shorter shard that leaves stale rows behind."""
+    F, n_max = 5, 192
+    st = ingest.DenseShardStager(F, n_max, width=width)
+    rng = np.random.default_rng(width)
+    for k, frames in enumerate((5, 3, 5)):
+        st.host_ready(k)
+        slot = st.host_slot(k)
+        slot.reset()
+        counts = rng.integers(0, n_max + 1, (frames, 2))
+        counts[0, 1], counts[frames - 1, 0] = 0, n_max
+        want_d = np.zeros((frames, 2, n_max, 64), np.uint8)
+        want_x = np.zeros((frames, 2, n_max, 2), np.float32)
+        for j, side in rng.permutation([(j, s) for j in range(frames) for s in range(2)]):
+            n = int(counts[j, side])
+            dsc = rng.integers(0, 256, (n, width), dtype=np.uint8)
+            pts = rng.random((n, 2), dtype=np.float32) * 1000
+            want_d[j, side, :n, :width], want_x[j, side, :n] = dsc, pts
+            assert slot.put(int(j), int(side), pts, dsc if n else None) == n
+        st.upload(k, frames)
+        d, x, c = st.device(k)
+        assert np.array_equal(c.cpu().numpy().reshape(frames, 2), counts)
+        assert np.array_equal(d.cpu().numpy().reshape(frames, 2, n_max, 64), want_d)
+        assert np.array_equal(x.cpu().numpy().reshape(frames, 2, n_max, 2), want_x)
+        assert st.bytes_per_shard(frames, k) == int(counts.sum()) * (width + 8) + 2 * frames * 12
+        st.release(k)
+    with pytest.raises(ValueError):
+        ingest.DenseShardStager(2, 64, width=61).host_slot(0).put(0, 0, np.zeros((300, 2)), np.zeros((300, 61), np.uint8))
+
+
+def test_unpack_treats_an_image_outside_the_dense_arrays_as_empty():
+    from slam_amd import _lib, ops
+    n_max, width, rows = 64, 61, 100
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dense = dev(np.full((rows, width), 7, np.uint8))
+    xy = dev(np.ones((rows, 2), np.float32))
+    row_ptr = dev(np.array([0, 90, -5, 60], np.int64))
+    count = dev(np.array([10, 20, 3, 999], np.int32))          # 90 + 20 > 100; negative start; 999 clamps to 64, 60 + 64 > 100
+    out_d = torch.full((4, n_max, 64), 255, dtype=torch.uint8, device="cuda")
+    out_x = torch.full((4, n_max, 2), -1.0, dtype=torch.float32, device="cuda")
+    out_c = torch.full((4,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().slam_unpack_detections(dense.data_ptr(), xy.data_ptr(), row_ptr.data_ptr(), count.data_ptr(), 4, n_max, width,
+                                                 rows, out_d.data_ptr(), out_x.data_ptr(), out_c.data_ptr(), ops._stream()))
+    assert out_c.cpu().tolist() == [10, 0, 0, 0]
+    d = out_d.cpu().numpy()
+    assert (d[0, :10, :61] == 7).all() and not d[0, :10, 61:].any() and not d[0, 10:].any() and not d[1:].any()
+    assert float(out_x[0, :10].min()) == 1.0 and not out_x[0, 10:].any() and not out_x[1:].any()
+
+
+def test_streamed_movie_in_the_dense_format_equals_resident_shard():
+    F = 29
+    cfg = SynthConfig(n_frames=F, n_features=500, seed=78, ragged=True)
+    desc, xy, count = SynthSequence(cfg).frames(0, F)
+    n_max = cfg.n_max
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    f0, f1 = consecutive_pairs(F)
+    whole = ShardTracker(F, F - 1, n_max).run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)),
+                                              dev(count.reshape(2 * F)), f0, f1, 1000 + np.arange(F - 1), unpack_mask=False)
+    pose, stats = ingest.track_movie_streamed(ArrayDetections(desc, xy, count), F, n_max, 9, workers=4, dense_width=61)
+    assert np.array_equal(pose, whole.pose) and np.array_equal(stats[:, :6], whole.stats[:, :6])
