@@ -205,7 +205,7 @@ int slam_refit_pnp(const double *h_K, const double *d_X, const void *d_xy1, int 
  * d_xy [n_img][n_max][2]) with 8 % fewer bytes over PCIe than uploading that layout itself.
  *   d_dense_desc [n_rows_total][desc_width]  descriptor rows at their own width (61 for AKAZE MLDB), any image order;
  *                                            4-byte aligned
- *   d_dense_xy   [n_rows_total][2]           KeyPoint.pt of the same rows
+ *   d_dense_xy   [n_rows_total][2]           KeyPoint.pt of the same rows; 8-byte aligned
  *   d_row_ptr    [n_img] int64               first dense row of image k;  d_count [n_img]: its rows
  * Every byte of d_desc / d_xy is written: rows past an image's count and bytes past desc_width are zero, so the result
  * equals a padded upload.  d_count_out [n_img]: the counts clamped to [0, n_max]; an image whose row range does not lie
