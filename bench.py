@@ -50,8 +50,8 @@ PMC_SUMMARY_FALLBACK = os.path.join("profiles", "r1_final_pmc_summary.json")
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=("trajectory", "stress", "loops"), default="trajectory",
                     help="trajectory = BASELINE configs[1] (N = 1) / configs[2] (N > 1), the headline; stress = configs[3] "
                          "(8k features, 60 %% outliers, 10 000 hypotheses per pair); loops = configs[4] (3450 frames x 5 candidates)")

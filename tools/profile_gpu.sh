@@ -15,7 +15,7 @@ cd "$GRAFT_REPO_ROOT"
 # --no-ingest / --no-dropin / --no-cpu-baseline: those legs run the step again in other settings (H2D copies overlapped,
 # Python drivers), which would mix other launches into the per-kernel averages; the timed region that bench.py's
 # roofline is computed from has none of them.
-B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ingest --no-dropin"
+B="python3 bench.py --no-cpu-baseline --no-ingest --no-dropin"     # default steps / warmup (20 / 5): the first launches of a process run below the sustained clock
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_default -- $B > $out/bench_default.json 2> $out/trace_default.err
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_chunks1 -- $B --chunks 1 > $out/bench_chunks1.json 2> $out/trace_chunks1.err
 P="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-ingest --no-dropin --chunks 1"
