@@ -45,20 +45,49 @@ def all_gather_rows(local: torch.Tensor, n_total: int, world: int, rank: int) ->
     return out[:n_total]
 
 
+_gather_buffers = {}
+
+
+def _gather_ctx(per: int, world: int, dev):
+    """Staging for gather_shard_results, allocated once per (block size, world, device): a page-locked row block each way
+    and the two device buffers of the collective, so a step pays for the copies and the all-gather, not for allocations."""
+    key = (per, world, str(dev))
+    ctx = _gather_buffers.get(key)
+    if ctx is None:
+        pin = dev.type == "cuda"
+        h_in = torch.zeros((per, 128), dtype=torch.uint8)
+        h_out = torch.empty((world * per, 128), dtype=torch.uint8)
+        ctx = _gather_buffers[key] = (h_in.pin_memory() if pin else h_in, h_out.pin_memory() if pin else h_out,
+                                      torch.zeros((per, 128), dtype=torch.uint8, device=dev),
+                                      torch.empty((world * per, 128), dtype=torch.uint8, device=dev))
+    return ctx
+
+
 def gather_shard_results(pose_local: np.ndarray, stats_local: np.ndarray, n_pairs_total: int, device=None):
     """pose_local float64[p, 3, 4], stats_local int32[p, 8] of this rank's pair block -> the full arrays on every rank.
     One collective: a pair's pose (96 bytes) and counters (32 bytes) travel as one 128-byte row."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
     if not dist.is_initialized():
         return pose_local, stats_local
-    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
-                                             if dist.get_backend() == "nccl" else torch.device("cpu"))
+    world = dist.get_world_size()
+    dev = _coll_device(device)
     p = len(pose_local)
-    row = np.empty((p, 128), np.uint8)
-    row[:, :96] = np.ascontiguousarray(pose_local, dtype=np.float64).reshape(p, 12).view(np.uint8)
-    row[:, 96:] = np.ascontiguousarray(stats_local, dtype=np.int32).reshape(p, 8).view(np.uint8)
-    full = all_gather_rows(torch.from_numpy(row).to(dev), n_pairs_total, world, rank).cpu().numpy()
+    per = -(-n_pairs_total // world)
+    if p > per:
+        raise ValueError("more local pairs than a block of the partition holds")
+    h_in, h_out, d_in, d_out = _gather_ctx(per, world, dev)
+    row = h_in.numpy()
+    row[:p, :96] = np.ascontiguousarray(pose_local, dtype=np.float64).reshape(p, 12).view(np.uint8)
+    row[:p, 96:] = np.ascontiguousarray(stats_local, dtype=np.int32).reshape(p, 8).view(np.uint8)
+    row[p:] = 0
+    if dev.type == "cuda":
+        d_in.copy_(h_in, non_blocking=True)
+        dist.all_gather_into_tensor(d_out, d_in)
+        h_out.copy_(d_out, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        full = h_out.numpy()[:n_pairs_total]
+    else:
+        dist.all_gather_into_tensor(h_out, h_in)
+        full = h_out.numpy()[:n_pairs_total]
     pose = np.ascontiguousarray(full[:, :96]).view(np.float64).reshape(-1, 3, 4)
     stats = np.ascontiguousarray(full[:, 96:]).view(np.int32).reshape(-1, 8)
     return pose, stats
