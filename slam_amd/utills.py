@@ -665,6 +665,100 @@ def whole_movie(first_left_ex_mat=M1, movie_len=None, seeds=None):
     return find_features_in_consecutive_frames_whole_movie(first_left_ex_mat, movie_len, seeds)[3]
 
 
+# == small host helpers of the reference module, kept so that its callers find them here ==
+TRIANGULATION_METERS_TO_PIX_DIFF = {450: 1, 250: 2, 150: 3, 120: 4, 90: 5}        # :35
+TRIANGULATION_REJ_METERS = 150                                                      # :36
+LEFT_CAM_TRANS_PATH = None      # :28 is a path on the reference author's machine; pass the KITTI poses file explicitly
+
+
+def get_matches_coor_and_kpts(matches, img1_kpts, img2_kpts):
+    """:199-211.  One row [img1 key-point index, x1, y1, x2, y2] per match."""
+    rows = []
+    for m in matches:
+        (x1, y1), (x2, y2) = img1_kpts[m.queryIdx].pt, img2_kpts[m.trainIdx].pt
+        rows.append([m.queryIdx, x1, y1, x2, y2])
+    return np.array(rows)
+
+
+def get_inliers_and_outliers_coor_for_rec(inliers_matches, outliers_matches, img1_kpts, img2_kpts):
+    """:214-217."""
+    return get_matches_coor(inliers_matches, img1_kpts, img2_kpts) + get_matches_coor(outliers_matches, img1_kpts, img2_kpts)
+
+
+def rodriguez_to_mat(R_vec, t_vec):
+    """:574-582.  [R|t] from a rotation vector (cv2.Rodrigues: R = cos(th) I + (1 - cos(th)) k k^T + sin(th) [k]x) and a
+    translation column."""
+    r = np.asarray(R_vec, dtype=np.float64).reshape(3)
+    th = float(np.sqrt(r @ r))
+    if th < np.finfo(np.float64).eps:
+        R = np.eye(3)
+    else:
+        k = r / th
+        kx = np.array([[0.0, -k[2], k[1]], [k[2], 0.0, -k[0]], [-k[1], k[0], 0.0]])
+        R = np.cos(th) * np.eye(3) + (1.0 - np.cos(th)) * np.outer(k, k) + np.sin(th) * kx
+    return np.hstack((R, np.asarray(t_vec, dtype=np.float64).reshape(3, 1)))
+
+
+def relative_camera_pos_4(left0_ex_mat, right0_ex_mat, left1_ex_mat, right1_ex_mat):
+    """:641-650."""
+    return tuple(relative_camera_pos(m) for m in (left0_ex_mat, right0_ex_mat, left1_ex_mat, right1_ex_mat))
+
+
+def euclidean_dist(pts_lst1, pts_lst2=None, dim="3d"):
+    """:739-746 (the square root of compute_square_dist, quirk of its "3d" branch included)."""
+    return np.sqrt(compute_square_dist(pts_lst1, pts_lst2, dim=dim))
+
+
+def get_ground_truth_transformations(left_cam_trans_path=LEFT_CAM_TRANS_PATH, movie_len=MOVIE_LEN):
+    """:771-782.  The first movie_len 3x4 matrices of a KITTI poses file (12 numbers per line)."""
+    if left_cam_trans_path is None:
+        raise FileNotFoundError("pass the path of the KITTI poses file (dataset/poses/00.txt)")
+    out = []
+    with open(left_cam_trans_path) as fh:
+        for _, line in zip(range(movie_len), fh):
+            out.append(np.array(line.split(), dtype=float).reshape(3, 4))
+    return out
+
+
+def compute_ground_truth_traj(left_cam_trans_path=LEFT_CAM_TRANS_PATH):
+    """:356-359."""
+    return left_cameras_trajectory(get_ground_truth_transformations(left_cam_trans_path))
+
+
+def far_or_neg_pts_rej(left0_matches_coor, right0_matches_coor):
+    """:928-937.  Disparity test: points nearer than TRIANGULATION_REJ_METERS and in front of the rig."""
+    disparity = left0_matches_coor[:, 0] - right0_matches_coor[:, 0]
+    return (disparity > TRIANGULATION_METERS_TO_PIX_DIFF[TRIANGULATION_REJ_METERS]) * (disparity > 0)
+
+
+def get_rand_track(track_len, tracks):
+    """:1000-1012.  Draws from `random` until a track of that length comes up (as the reference: forever if there is none)."""
+    import random
+    while True:
+        t = tracks[random.randint(0, len(tracks) - 1)]
+        if t.get_track_len() == track_len:
+            return t
+
+
+def compare_dbs_median_tracks_len(db_path, percentage):
+    """:940-942."""
+    from . import types
+    return types.load(db_path).tracks_median_len(percentage)
+
+
+def mahalanobis_dist(delta, cov):
+    """:1052-1054."""
+    return (delta.T @ np.linalg.inv(cov) @ delta) ** 0.5
+
+
+def compute_whole_movie_time(first_left_ex_mat=M1):
+    """:362-370.  -> (relative poses, minutes)."""
+    import time
+    t0 = time.perf_counter()
+    rel = find_features_in_consecutive_frames_whole_movie(first_left_ex_mat)[3]
+    return rel, (time.perf_counter() - t0) / 60
+
+
 # == Ex7: loop-closure candidate validation ==
 def create_little_tracks(first_frame_features_obj, second_frame_features_obj, first_frame_id, second_frame_id):
     """:1149-1167."""

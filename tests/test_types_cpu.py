@@ -3,6 +3,7 @@ features (golden db_* arrays were recorded from the reference's DataBase, tests/
 import pickle
 
 import numpy as np
+import pytest
 
 from slam_amd import types
 
@@ -69,3 +70,43 @@ def test_track_and_frame_accessors():
     assert t.get_right_locations_in_specific_frames([5]) == [(8., 5.5)]
     fr = types.Frame(2, np.hstack([np.eye(3), [[1.], [2.], [3.]]]))
     assert np.array_equal(fr.get_pose(), [-1., -2., -3.]) and fr.get_tracks_num() == 0
+
+
+def test_small_reference_helpers(tmp_path):
+    """The reference module's small host helpers that its callers import from utills (no device work)."""
+    import random
+    from scipy.spatial.transform import Rotation
+    from slam_amd import utills as U
+    from slam_amd.types import DMatch, KeyPoint, Track, Feature
+    k1 = [KeyPoint(1.5, 2.5), KeyPoint(10, 20)]
+    k2 = [KeyPoint(3, 4), KeyPoint(30, 40), KeyPoint(5, 6)]
+    ms = [DMatch(1, 2, 7), DMatch(0, 1, 3)]
+    assert U.get_matches_coor_and_kpts(ms, k1, k2).tolist() == [[1, 10, 20, 5, 6], [0, 1.5, 2.5, 30, 40]]
+    a, b, c, d = U.get_inliers_and_outliers_coor_for_rec(ms[:1], ms[1:], k1, k2)
+    assert a.tolist() == [[10, 20]] and b.tolist() == [[5, 6]] and c.tolist() == [[1.5, 2.5]] and d.tolist() == [[30, 40]]
+    r = np.array([[0.3], [-0.2], [0.5]])
+    T = U.rodriguez_to_mat(r, np.array([[1.0], [2.0], [3.0]]))
+    assert np.allclose(T[:, :3], Rotation.from_rotvec(r.ravel()).as_matrix(), atol=1e-15) and T[:, 3].tolist() == [1, 2, 3]
+    assert np.array_equal(U.rodriguez_to_mat(np.zeros(3), np.zeros(3))[:, :3], np.eye(3))
+    M = np.hstack([np.eye(3), [[1.0], [2.0], [3.0]]])
+    assert all(np.array_equal(p, [-1, -2, -3]) for p in U.relative_camera_pos_4(M, M, M, M))
+    P = np.array([[3.0, 4.0, 0.0]])
+    assert U.euclidean_dist(P).tolist() == [np.sqrt(5.0)] and U.euclidean_dist(P[:, :2], dim="2d").tolist() == [5.0]
+    poses = tmp_path / "00.txt"
+    poses.write_text("\n".join(" ".join(str(float(i + j)) for j in range(12)) for i in range(5)) + "\n")
+    gt = U.get_ground_truth_transformations(str(poses), 3)
+    assert len(gt) == 3 and gt[2].shape == (3, 4) and gt[2][0, 0] == 2.0 and gt[1][2, 3] == 12.0
+    assert U.left_cameras_trajectory(U.get_ground_truth_transformations(str(poses), 5)).shape == (5, 3)
+    with pytest.raises(FileNotFoundError):
+        U.get_ground_truth_transformations()
+    l0 = np.array([[100.0, 5], [50.0, 5], [10.0, 5]]); r0 = np.array([[90.0, 5], [48.0, 5], [12.0, 5]])
+    assert U.far_or_neg_pts_rej(l0, r0).tolist() == [True, False, False]
+    tr = []
+    for i, n in enumerate((2, 3, 2)):
+        t = Track(i)
+        for f in range(n):
+            t.add_feature(f, Feature(0, 0, 0.0, 0.0, 0.0, 0.0))
+        tr.append(t)
+    random.seed(1)
+    assert U.get_rand_track(3, tr).get_id() == 1
+    assert abs(U.mahalanobis_dist(np.array([3.0, 4.0]), np.diag([9.0, 16.0])) - np.sqrt(2.0)) < 1e-15
