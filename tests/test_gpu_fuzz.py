@@ -1,0 +1,89 @@
+"""Randomised shapes against the C oracle: the single and the batched matcher in all three modes on sizes drawn around
+the tile / wavefront / split boundaries, tie-heavy and random bytes, both norms, three descriptor widths; and the join
+on top of them.  A fixed seed keeps the run reproducible; SLAM_FUZZ_ROUNDS raises the number of cases."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import c_oracle
+import slam_oracle as orc
+from slam_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+ROUNDS = int(os.environ.get("SLAM_FUZZ_ROUNDS", 40))
+EDGES = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1999, 2048, 2049, 4097]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _size(rng):
+    return int(rng.choice(EDGES)) if rng.random() < 0.6 else int(rng.integers(1, 3000))
+
+
+def _desc(rng, n, width):
+    values = int(rng.choice([2, 4, 256]))                 # few byte values: ties everywhere
+    d = np.zeros((n, 64), np.uint8)
+    d[:, :width] = rng.integers(0, values, (n, width), dtype=np.uint8)
+    if rng.random() < 0.5 and n > 3:
+        d[rng.integers(0, n, n // 3)] = d[rng.integers(0, n, n // 3)]          # exact duplicates
+    return d
+
+
+def _check_keys(k1, k2, q, t, norm, mode, width):
+    idx, dist = (x.cpu().numpy() for x in ops.unpack_keys(k1))
+    if mode == _lib.SLAM_MATCH_KNN2:
+        D = orc.hamming_matrix(q[:, :width], t[:, :width], norm)
+        order, d = orc.knn2_from_matrix(D)
+        assert np.array_equal(idx, order[:, 0]) and np.array_equal(dist, d[:, 0])
+        if len(t) > 1:
+            idx2, dist2 = (x.cpu().numpy() for x in ops.unpack_keys(k2))
+            assert np.array_equal(idx2, order[:, 1]) and np.array_equal(dist2, d[:, 1])
+        return
+    wq, wt, wd = c_oracle.match_crosscheck(q[:, :width], t[:, :width], norm, mutual=mode == _lib.SLAM_MATCH_CROSSCHECK_MUTUAL)
+    got = np.nonzero(idx >= 0)[0]
+    assert np.array_equal(got, wq) and np.array_equal(idx[got], wt) and np.array_equal(dist[got], wd)
+
+
+def test_single_matcher_random_shapes():
+    rng = np.random.default_rng(2024)
+    for case in range(ROUNDS):
+        nq, nt, width = _size(rng), _size(rng), int(rng.choice([32, 61, 64]))
+        norm = int(rng.choice([_lib.SLAM_NORM_HAMMING, _lib.SLAM_NORM_HAMMING2]))
+        mode = int(rng.choice([_lib.SLAM_MATCH_CROSSCHECK, _lib.SLAM_MATCH_KNN2, _lib.SLAM_MATCH_CROSSCHECK_MUTUAL]))
+        q, t = _desc(rng, nq, width), _desc(rng, nt, width)
+        if rng.random() < 0.3:
+            t[: min(nq, nt)] = q[: min(nq, nt)]
+        k1, k2 = ops.match_keys(dev(q), dev(t), norm, mode)
+        try:
+            _check_keys(k1, k2, q, t, norm, mode, width)
+        except AssertionError:
+            raise AssertionError(f"case {case}: {nq} x {nt}, width {width}, norm {norm}, mode {mode}")
+
+
+def test_batched_matcher_random_batches():
+    rng = np.random.default_rng(77)
+    for case in range(max(4, ROUNDS // 4)):
+        n_max = int(rng.choice([64, 192, 1024, 2048]))
+        n_img = int(rng.integers(2, 9))
+        width = int(rng.choice([32, 61, 64]))
+        counts = np.array([min(n_max, _size(rng)) if rng.random() < 0.9 else 0 for _ in range(n_img)], np.int32)
+        desc = np.stack([np.vstack([_desc(rng, int(c), width), rng.integers(0, 256, (n_max - int(c), 64), dtype=np.uint8)])
+                         for c in counts])                 # rows past the count hold garbage on purpose
+        n_prob = int(rng.choice([1, 3, 17, 90]))
+        pq, pt = rng.integers(0, n_img, n_prob).astype(np.int32), rng.integers(0, n_img, n_prob).astype(np.int32)
+        norm = int(rng.choice([_lib.SLAM_NORM_HAMMING, _lib.SLAM_NORM_HAMMING2]))
+        mode = int(rng.choice([_lib.SLAM_MATCH_CROSSCHECK, _lib.SLAM_MATCH_KNN2, _lib.SLAM_MATCH_CROSSCHECK_MUTUAL]))
+        k1, k2 = ops.match_keys_batched(dev(desc), dev(counts), dev(pq), dev(pt), norm=norm, mode=mode)
+        for k in range(min(n_prob, 6)):
+            nq, nt = int(counts[pq[k]]), int(counts[pt[k]])
+            if nq == 0 or nt == 0:
+                assert (ops.unpack_keys(k1[k])[0][:max(nq, 1)].cpu().numpy() < 0).all()
+                continue
+            try:
+                _check_keys(k1[k, :nq], None if k2 is None else k2[k, :nq], desc[pq[k], :nq], desc[pt[k], :nt], norm, mode, 64)
+            except AssertionError:
+                raise AssertionError(f"case {case} problem {k}: n_max {n_max}, {nq} x {nt}, norm {norm}, mode {mode}, batch {n_prob}")
