@@ -15,10 +15,12 @@ for _p in (_ROOT, os.path.join(_ROOT, "oracle")):
 _SEQ = None
 _KW = None
 _MATCHER = None
+_SLACK = 64
 
 
-def _init(cfg_kwargs, ransac_kw, matcher=None):
-    global _SEQ, _KW, _MATCHER
+def _init(cfg_kwargs, ransac_kw, matcher=None, slack=64):
+    global _SEQ, _KW, _MATCHER, _SLACK
+    _SLACK = slack
     import c_oracle
     import slam_oracle as orc
     from slam_amd.synth import SynthConfig, SynthSequence
@@ -51,10 +53,15 @@ def _pair(job):
     np.random.seed(int(seed))
     st = {}
     with np.errstate(all="ignore"):
-        w = orc.track_pair(_frame(f0), _frame(f1), stats=st, matcher=_MATCHER, **_KW)
+        try:
+            w = orc.track_pair(_frame(f0), _frame(f1), stats=st, matcher=_MATCHER, **_KW)
+        except ValueError as e:                      # np.random.randint(0, 0, 4): nothing tracked (utils/utills.py:502)
+            if str(e) != "low >= high":
+                raise
+            return key, np.zeros((0, 4), np.int32), np.zeros(0, np.uint8), -1, -1, -1, None, 0
     np.random.seed(int(seed))
     n, noisy = len(w["kp"]), 0
-    for _ in range(st["draws"] + 64):                # + slack: the other side may have consumed a few more draws
+    for _ in range(st["draws"] + _SLACK):            # + slack: the other side may have consumed a few more draws
         i = np.random.randint(0, n, 4)
         noisy += int(i[3] in i[:3])
     return key, w["kp"].astype(np.int32), np.packbits(w["mask"]), st["iterations"], st["draws"], st["best_draw"], w["T"], noisy
@@ -66,12 +73,13 @@ def cpu_share():
     return max(1, min(n, 16))
 
 
-def run(cfg_kwargs, jobs, ransac_kw=None, workers=None, matcher=None):
+def run(cfg_kwargs, jobs, ransac_kw=None, workers=None, matcher=None, slack=64):
     """jobs: iterable of (key, frame0, frame1, seed).  Returns {key: result tuple without the key}.
-    matcher: None (cross-check, legacy rule), "mutual" or "knn_ratio"."""
+    matcher: None (cross-check, legacy rule), "mutual" or "knn_ratio".  slack: draws beyond the oracle's own that are
+    also examined for a repeated fourth index."""
     workers = workers or cpu_share()
     out = {}
-    with mp.get_context("spawn").Pool(workers, initializer=_init, initargs=(cfg_kwargs, ransac_kw or {}, matcher)) as pool:
+    with mp.get_context("spawn").Pool(workers, initializer=_init, initargs=(cfg_kwargs, ransac_kw or {}, matcher, slack)) as pool:
         for r in pool.imap_unordered(_pair, list(jobs), chunksize=4):
             out[r[0]] = r[1:]
     return out

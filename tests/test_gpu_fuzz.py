@@ -87,3 +87,54 @@ def test_batched_matcher_random_batches():
                 _check_keys(k1[k, :nq], None if k2 is None else k2[k, :nq], desc[pq[k], :nq], desc[pt[k], :nt], norm, mode, 64)
             except AssertionError:
                 raise AssertionError(f"case {case} problem {k}: n_max {n_max}, {nq} x {nt}, norm {norm}, mode {mode}, batch {n_prob}")
+
+
+def test_whole_pipeline_on_random_small_sequences_against_the_oracle():
+    """slam_track_pairs on sequences drawn at random -- a handful to a few hundred features per image, different outlier
+    mixes, consecutive and far-apart frame pairs, the three match methods, one to three chunks -- against the CPU oracle
+    pair by pair: tracked sets always; supporter mask, loop counters and pose wherever no draw repeats its fourth index
+    (DESIGN.md section 2); None poses where the oracle has none."""
+    import _oracle_pool
+    from slam_amd.config import REGULAR_KNN, HotPathConfig
+    from slam_amd.pipeline import ShardTracker
+    from slam_amd.synth import SynthConfig, SynthSequence
+    rng = np.random.default_rng(31)
+    methods = [(None, {}), ("mutual", {"crosscheck_rule": "mutual"}), ("knn_ratio", {"match_method": REGULAR_KNN})]
+    checked = clean = no_pose = 0
+    for case in range(6):
+        F = 10
+        cfg_kw = dict(n_frames=F, n_features=int(rng.choice([6, 24, 70, 200, 450, 600])), seed=int(rng.integers(1, 10 ** 6)),
+                      true_frac=float(rng.choice([0.3, 0.7, 0.9])), spawn_per_frame=int(rng.choice([4, 20, 60])),
+                      ragged=int(rng.choice([3, 17])), gross_frac=float(rng.choice([0.0, 0.04, 0.3])),
+                      mismatch_frac=float(rng.choice([0.0, 0.1])))
+        cfg = SynthConfig(**cfg_kw)
+        desc, xy, count = SynthSequence(cfg).frames(0, F)
+        n_max = cfg.n_max
+        f0 = np.concatenate([np.arange(F - 1), [0, 7, 2]]).astype(np.int32)
+        f1 = np.concatenate([np.arange(1, F), [5, 3, 2]]).astype(np.int32)            # far apart, backwards, a frame with itself
+        seeds = 500 + 13 * case + np.arange(len(f0))
+        how, kw = methods[case % 3]
+        trk = ShardTracker(F, len(f0), n_max, HotPathConfig(**kw), n_chunks=1 + case % 3)
+        res = trk.run(dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)), f0, f1, seeds)
+        kp = res.tracked_kp.cpu().numpy()
+        want = _oracle_pool.run(cfg_kw, [(p, int(f0[p]), int(f1[p]), int(seeds[p])) for p in range(len(f0))], workers=4,
+                                matcher=how, slack=0)     # small tracked sets: only the draws the loop consumed
+        for p in range(len(f0)):
+            wkp, wmask, wit, wdraws, wbest, wT, noisy = want[p]
+            n = len(wkp)
+            assert res.stats[p, 0] == n and np.array_equal(kp[p, :n], wkp), (case, p)
+            checked += 1
+            if n == 0:                                # the reference raises here (np.random.randint(0, 0, 4))
+                assert wit == -1 and res.stats[p, 5] & _lib.SLAM_PAIR_EMPTY and not res.ok[p], (case, p)
+                continue
+            if noisy == 0:
+                clean += 1
+                assert np.array_equal(np.packbits(res.mask[p, :n]), wmask), (case, p)
+                assert (res.stats[p, 2], res.stats[p, 3], res.stats[p, 4]) == (wit, wdraws, wbest), (case, p)
+                if wT is None:
+                    assert not res.ok[p] and np.isnan(res.pose[p]).all(), (case, p)
+                    no_pose += 1
+                else:
+                    assert res.ok[p] and np.linalg.norm(res.pose[p] - wT) / np.linalg.norm(wT) <= 1e-5, (case, p)
+    assert checked == 6 * 12 and clean >= 15
+    print(f"pipeline fuzz: {checked} pairs, {clean} without a noisy draw, {no_pose} of them without a pose")
