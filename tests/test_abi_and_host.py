@@ -122,3 +122,20 @@ def test_track_pairs_rejects_bad_arguments_before_touching_the_gpu():
     assert rc == _lib.SLAM_E_INVALID and "pair 1" in msg and "outside" in msg
     with pytest.raises(_lib.SlamError):
         _lib.check(rc)
+
+
+def test_the_package_never_touches_the_oracle_or_the_reference_tree():
+    """The oracle is the checker (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg); nothing under slam_amd/
+    may import it, put its directory on sys.path, or open the reference checkout at run time."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slam_amd")
+    bad = []
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if not f.endswith((".py", ".hip", ".cpp", ".h")):
+                continue
+            text = open(os.path.join(dirpath, f), encoding="utf-8").read()
+            for line_no, line in enumerate(text.splitlines(), 1):
+                code = line.split("#", 1)[0]
+                if re.search(r"\b(import|from)\s+(slam_oracle|c_oracle)\b|[\"']oracle[\"'/]|open\([^)]*/root/reference", code):
+                    bad.append(f"{f}:{line_no}: {line.strip()}")
+    assert not bad, bad
