@@ -54,6 +54,7 @@ extern "C" {
 #define SLAM_E_HIP (-3)         /* a HIP runtime call failed */
 #define SLAM_E_EMPTY (-4)       /* empty tracked set: the reference raises ValueError (utills.py:502) */
 #define SLAM_E_DUPLICATE (-5)   /* slam_chain_tracks: a key-point appears twice inside one pair */
+#define SLAM_E_HOST (-6)        /* host-side failure inside the library (out of host memory, a worker thread failed) */
 
 const char *slam_version(void);
 const char *slam_last_error_string(void);

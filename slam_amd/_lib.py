@@ -19,7 +19,7 @@ SLAM_MATCH_CROSSCHECK_MUTUAL = 2
 SLAM_KEY_SHIFT = 20
 SLAM_KEY_NONE = 0xFFFFFFFF
 SLAM_MATCH_NOALLOC_MAX_ROWS = 8192
-SLAM_OK, SLAM_E_INVALID, SLAM_E_WORKSPACE, SLAM_E_HIP, SLAM_E_EMPTY, SLAM_E_DUPLICATE = 0, -1, -2, -3, -4, -5
+SLAM_OK, SLAM_E_INVALID, SLAM_E_WORKSPACE, SLAM_E_HIP, SLAM_E_EMPTY, SLAM_E_DUPLICATE, SLAM_E_HOST = 0, -1, -2, -3, -4, -5, -6
 
 SLAM_PAIR_OK, SLAM_PAIR_EMPTY, SLAM_PAIR_FEW, SLAM_PAIR_DRAW_CAP = 1, 2, 4, 8
 

@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <exception>
+#include <new>
 
 #include "../../include/slam_amd.h"
 
@@ -26,6 +28,27 @@ void slam_set_error(const char *fmt, ...);
             return SLAM_E_INVALID;         \
         }                                  \
     } while (0)
+
+// No C++ exception crosses the C ABI: entry points that allocate host memory or use the worker pool are written as
+// function-try-blocks closed by this macro (`extern "C" int f(...) try { ... } SLAM_CATCH_ALL("f")`).  `cleanup` runs
+// first (e.g. draining streams so that no device work of the failed call outlives it).
+#define SLAM_CATCH_ALL_WITH(name, cleanup)                            \
+    catch (const std::bad_alloc &) {                                  \
+        cleanup;                                                      \
+        slam_set_error(name ": out of host memory");                  \
+        return SLAM_E_HOST;                                           \
+    }                                                                 \
+    catch (const std::exception &e_) {                                \
+        cleanup;                                                      \
+        slam_set_error(name ": host failure: %s", e_.what());         \
+        return SLAM_E_HOST;                                           \
+    }                                                                 \
+    catch (...) {                                                     \
+        cleanup;                                                      \
+        slam_set_error(name ": host failure");                        \
+        return SLAM_E_HOST;                                           \
+    }
+#define SLAM_CATCH_ALL(name) SLAM_CATCH_ALL_WITH(name, (void)0)
 
 static inline int slam_div_up(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t slam_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

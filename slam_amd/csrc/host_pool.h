@@ -14,6 +14,7 @@
 #pragma once
 #include <condition_variable>
 #include <cstdlib>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -26,7 +27,11 @@ public:
         return pool;
     }
     explicit HostPool(int n_threads) {
-        for (int t = 1; t < n_threads; ++t) threads.emplace_back([this] { loop(); });
+        try {
+            for (int t = 1; t < n_threads; ++t) threads.emplace_back([this] { loop(); });
+        } catch (...) {
+            // the system refused another thread: the pool works with those it has (the caller is always one of them)
+        }
     }
     ~HostPool() {
         {
@@ -40,7 +45,9 @@ public:
     HostPool(const HostPool &) = delete;
     HostPool &operator=(const HostPool &) = delete;
 
-    // runs job(0) .. job(n_chunks - 1), each exactly once, on the pool's threads and the caller; returns when all are done
+    // runs job(0) .. job(n_chunks - 1), each exactly once, on the pool's threads and the caller; returns when all are
+    // done.  A job that throws does not take its thread (and the process) down: the first exception is kept and thrown
+    // again here, on the caller, after every chunk has finished.
     void run(int n_chunks, const std::function<void(int)> &job) {
         if (n_chunks <= 0) return;
         std::lock_guard<std::mutex> serial(gate);
@@ -51,14 +58,21 @@ public:
             total = n_chunks;
             next = 0;
             pending = n_chunks;
+            failure = nullptr;
             gen = ++generation;
         }
         cv_work.notify_all();
         work(gen);
-        std::unique_lock<std::mutex> lk(m);
-        cv_done.wait(lk, [&] { return pending == 0; });
-        fn = nullptr;
-        total = 0;
+        std::exception_ptr failed;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return pending == 0; });
+            fn = nullptr;
+            total = 0;
+            failed = failure;
+            failure = nullptr;
+        }
+        if (failed) std::rethrow_exception(failed);
     }
     int workers() const { return (int)threads.size() + 1; }
 
@@ -89,8 +103,14 @@ private:
                 c = next++;
                 f = fn;
             }
-            (*f)(c);
+            std::exception_ptr thrown;
+            try {
+                (*f)(c);
+            } catch (...) {
+                thrown = std::current_exception();
+            }
             std::lock_guard<std::mutex> lk(m);
+            if (thrown && !failure) failure = thrown;
             if (--pending == 0) cv_done.notify_all();
         }
     }
@@ -110,6 +130,7 @@ private:
     std::mutex gate, m;
     std::condition_variable cv_work, cv_done;
     const std::function<void(int)> *fn = nullptr;
+    std::exception_ptr failure;
     int next = 0, total = 0, pending = 0;
     unsigned long generation = 0;
     bool stop = false;

@@ -93,8 +93,8 @@ extern "C" int slam_unpack_detections(const uint8_t *d_dense_desc, const float *
     SLAM_REQUIRE(desc_width >= 1 && desc_width <= 64, "slam_unpack_detections: descriptor width must be 1 .. 64 bytes");
     SLAM_REQUIRE(n_img <= 65535 && n_rows_total >= 0, "slam_unpack_detections: at most 65535 images per call");
     SLAM_REQUIRE(((uintptr_t)d_dense_desc & 3) == 0 && ((uintptr_t)d_dense_xy & 7) == 0 && ((uintptr_t)d_xy & 7) == 0 &&
-                     ((uintptr_t)d_desc & 3) == 0,
-                 "slam_unpack_detections: d_dense_desc / d_desc must be 4-byte aligned, d_dense_xy / d_xy 8-byte aligned");
+                     ((uintptr_t)d_desc & 3) == 0 && ((uintptr_t)d_row_ptr & 7) == 0,
+                 "slam_unpack_detections: d_dense_desc / d_desc must be 4-byte aligned, d_dense_xy / d_xy / d_row_ptr 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(unpack_desc_kernel, dim3(n_max / UR, n_img), dim3(256), 0, st, d_dense_desc,
                        d_row_ptr, d_count, n_max, desc_width, (long)n_rows_total, (uint32_t *)d_desc, d_count_out);

@@ -628,7 +628,7 @@ extern "C" int slam_track_last_timing(double *h_ms8) {
     return SLAM_OK;
 }
 
-extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *io, void *stream) {
+extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *io, void *stream) try {
     const double t_begin = now_ms();
     hipStream_t st = (hipStream_t)stream;
     SLAM_REQUIRE(cfg && io, "slam_track_pairs: null config/io");
@@ -767,3 +767,5 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
     g_timing[7] = n_launch;
     return SLAM_OK;
 }
+// a host failure (allocation, a worker's exception): wait for whatever the call had queued, on every stream it may have used
+SLAM_CATCH_ALL_WITH("slam_track_pairs", (void)hipDeviceSynchronize())

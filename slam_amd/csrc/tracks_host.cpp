@@ -18,7 +18,7 @@
 extern "C" int slam_chain_tracks(const int32_t *h_kp, const int64_t *h_pair_ptr, int32_t n_pairs, int32_t n_kp,
                                  const float *h_xy, int32_t n_max, int64_t *h_track_ptr, int32_t *h_obs_frame,
                                  int32_t *h_obs_kp, double *h_obs_xy, int64_t *h_frame_ptr, int64_t *h_frame_tracks,
-                                 int64_t *h_n_tracks, int64_t *h_n_obs) {
+                                 int64_t *h_n_tracks, int64_t *h_n_obs) try {
     if (n_pairs < 0 || n_kp < 0 || !h_pair_ptr || !h_track_ptr || !h_frame_ptr || !h_n_tracks || !h_n_obs) {
         slam_set_error("slam_chain_tracks: bad arguments");
         return SLAM_E_INVALID;
@@ -124,3 +124,4 @@ extern "C" int slam_chain_tracks(const int32_t *h_kp, const int64_t *h_pair_ptr,
     *h_n_obs = n_obs;
     return SLAM_OK;
 }
+SLAM_CATCH_ALL("slam_chain_tracks")

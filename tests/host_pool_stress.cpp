@@ -1,8 +1,10 @@
 // ThreadSanitizer stress of slam_amd/csrc/host_pool.h (built and run by tests/test_host_pool_cpu.py):
 // jobs of alternating sizes back to back, as slam_track_pairs issues them (P/64-way replay, then rows/16-way later
-// rounds); every chunk must run exactly once and no chunk may still be running when run() returns.
+// rounds); every chunk must run exactly once and no chunk may still be running when run() returns; a chunk that throws
+// reaches the caller as an exception, not the process as std::terminate.
 #include <atomic>
 #include <cstdio>
+#include <stdexcept>
 #include <vector>
 
 #include "../slam_amd/csrc/host_pool.h"
@@ -37,6 +39,24 @@ int main() {
     long want = 0;
     for (int it = 0; it < 2000; ++it) want += 4 * (100 + it % 13);
     if (total.load() != want) ++bad;
+    // a job that throws: the exception comes back on the caller after every chunk has run, no thread is lost and the
+    // pool serves the next job as before
+    for (int it = 0; it < 200; ++it) {
+        std::atomic<int> ran{0};
+        bool caught = false;
+        try {
+            parallel_for(pool, 64, 4, [&](int a, int) {
+                ran.fetch_add(1);
+                if (a == 8 * (it % 8)) throw std::runtime_error("chunk failed");
+            });
+        } catch (const std::runtime_error &) {
+            caught = true;
+        }
+        if (!caught || ran.load() != 8) ++bad;
+        std::atomic<int> sum{0};
+        parallel_for(pool, 64, 4, [&](int a, int e) { sum.fetch_add(e - a); });
+        if (sum.load() != 64) ++bad;
+    }
     std::printf("bad=%ld\n", bad);
     return bad ? 1 : 0;
 }

@@ -205,3 +205,33 @@ def test_array_database_array_file_round_trip(tmp_path):
     with pytest.raises(ValueError):
         np.savez(str(tmp_path / "other.npz"), format=np.array("something else"))
         ArrayDataBase.load_arrays(str(tmp_path / "other.npz"))
+
+
+_NOMEM_SCRIPT = r"""
+import ctypes, resource, sys
+L = ctypes.CDLL(sys.argv[1])
+L.slam_last_error_string.restype = ctypes.c_char_p
+vm_kb = int([l for l in open('/proc/self/status') if l.startswith('VmSize')][0].split()[1])
+limit = vm_kb * 1024 + (256 << 20)
+resource.setrlimit(resource.RLIMIT_AS, (limit, limit))
+ptr = (ctypes.c_int64 * 1)(0)
+track_ptr = (ctypes.c_int64 * 2)()
+frame_ptr = (ctypes.c_int64 * 2)()
+nt, no = ctypes.c_int64(-1), ctypes.c_int64(-1)
+rc = L.slam_chain_tracks(None, ptr, 0, 1 << 28, None, 0, track_ptr, None, None, None, frame_ptr, None,
+                         ctypes.byref(nt), ctypes.byref(no))
+print(rc, L.slam_last_error_string().decode())
+"""
+
+
+def test_chain_tracks_reports_host_out_of_memory_instead_of_terminating():
+    """No C++ exception crosses the C ABI: with the address space capped, the 1 GiB key-point tables of a 2^28-row image
+    cannot be allocated and the call returns SLAM_E_HOST with a message (it used to end the process in std::terminate)."""
+    import subprocess
+    import sys
+
+    from slam_amd import _lib
+    p = subprocess.run([sys.executable, "-c", _NOMEM_SCRIPT, _lib.LIB_PATH], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    rc, msg = p.stdout.strip().split(" ", 1)
+    assert int(rc) == _lib.SLAM_E_HOST and "out of host memory" in msg
