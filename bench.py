@@ -472,13 +472,53 @@ def _oracle():
     import c_oracle
     import slam_oracle as orc
     orc.bf_match = lambda a, b, norm=7: c_oracle.match_crosscheck_w64(c_oracle.pad64(a), c_oracle.pad64(b), norm)
+    if hasattr(orc, "_port_pnp"):
+        orc.pnp = orc._port_pnp                    # undo _bind_cv2
     return orc
 
 
-def _oracle_pair(job):
-    """One frame pair through the CPU oracle (module-level so that a process pool can run it)."""
+def _try_cv2():
+    try:
+        import cv2
+        return cv2
+    except Exception:                              # not installed in the build image or on the GPU box
+        return None
+
+
+def _bind_cv2(orc, cv2):
+    """The oracle's per-pair driver with the arithmetic the reference leaves to OpenCV bound to the installed cv2, called
+    as the reference calls it: cv2.BFMatcher(norm, crossCheck=True).match (utils/utills.py:65-66) and cv2.solvePnP +
+    cv2.Rodrigues (:585-596, :574-582).  Everything else (rect test, join, triangulation, consensus, the adaptive loop)
+    is the reference's own numpy arithmetic, restated in the oracle."""
+    if not hasattr(orc, "_port_pnp"):
+        orc._port_pnp = orc.pnp
+
+    def bf_match(a, b, norm=7):
+        ms = cv2.BFMatcher(int(norm), crossCheck=True).match(np.ascontiguousarray(a, dtype=np.uint8), np.ascontiguousarray(b, dtype=np.uint8))
+        ms = sorted(ms, key=lambda m: m.queryIdx)
+        return (np.array([m.queryIdx for m in ms], np.int32), np.array([m.trainIdx for m in ms], np.int32),
+                np.array([int(round(m.distance)) for m in ms], np.int32))
+
+    def pnp(obj, img, calib, flag):
+        ok, rvec, tvec = cv2.solvePnP(np.ascontiguousarray(obj, dtype=np.float64), np.ascontiguousarray(img, dtype=np.float64),
+                                      np.asarray(calib, dtype=np.float64), None, flags=int(flag))
+        if not ok:
+            return None
+        return np.hstack([np.asarray(cv2.Rodrigues(rvec)[0], dtype=np.float64), np.asarray(tvec, dtype=np.float64).reshape(3, 1)])
+
+    orc.bf_match, orc.pnp = bf_match, pnp
+    return orc
+
+
+def _oracle_pair(job, cv2=None):
+    """One frame pair through the CPU oracle (module-level so that a process pool can run it); with cv2, through the
+    oracle's driver bound to the installed OpenCV."""
     a, b, seed = job
     orc = _oracle()
+    if cv2 is not None:
+        a, b = dict(a), dict(b)
+        a.pop("stereo", None)
+        orc = _bind_cv2(orc, cv2)
     a["stereo"] = orc.stereo_match(a["dsc_l"], a["dsc_r"], a["xy_l"], a["xy_r"])   # carried over from the previous pair
     np.random.seed(int(seed))
     t0 = time.perf_counter()
@@ -529,6 +569,10 @@ def cpu_baseline(args, leg):
                                 "note": "a pair can differ only where a draw repeats its fourth index and AP3P picks its "
                                         "root on rounding noise (DESIGN.md section 2; over the whole movie 13 of 3449 masks, 74 of 3449 iteration counts)"},
            "cpu_model": _cpu_model(), "host_cpus_visible": os.cpu_count()}
+    cv2 = _try_cv2()
+    if cv2 is not None:
+        out["cv2_reference_path"] = _cv2_leg(cv2, picks, js, res, kp, mask)
+    _oracle()                                                              # the port's own bindings again
     # all cores: the job's CPU share (OMP_NUM_THREADS is set to it on the GPU box; os.cpu_count() shows the whole machine)
     cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or len(os.sched_getaffinity(0)), 16))
     if cores > 1 and args.cpu_pairs_all_cores > 0:
@@ -543,6 +587,35 @@ def cpu_baseline(args, leg):
         out["all_cores"] = {"value": round(len(js) / wall, 3), "unit": "frame-pairs/s", "cores": cores,
                             "sample": f"{len(js)} evenly spaced frame pairs over {cores} worker processes, wall clock"}
     return out
+
+
+def _cv2_leg(cv2, picks, js, res, kp, mask, limit=48):
+    """Only where `import cv2` succeeds ("if cv2 is importable, the reference-shaped cv2 path"): the same
+    sample pairs with BFMatcher / solvePnP / Rodrigues from the installed OpenCV, one thread, and how the GPU results
+    compare with THAT -- the comparison DESIGN.md section 2 calls unpinned where cv2 is absent."""
+    step = max(1, len(picks) // limit)
+    t_total, n, eq_kp, eq_mask, worst = 0.0, 0, 0, 0, 0.0
+    try:
+        threads = cv2.getNumThreads()
+        cv2.setNumThreads(1)
+    except Exception:
+        threads = None
+    for p, job in list(zip(picks, js))[::step]:
+        dt, _, w_kp, w_mask, w_T = _oracle_pair(job, cv2=cv2)
+        t_total += dt
+        n += 1
+        T = len(w_kp)
+        same = bool(res.stats[p, 0] == T and np.array_equal(kp[p, :T], w_kp))
+        eq_kp += same
+        eq_mask += bool(same and np.array_equal(mask[p, :T], w_mask))
+        if same and w_T is not None and np.isfinite(res.pose[p]).all():
+            worst = max(worst, float(np.linalg.norm(res.pose[p] - w_T) / np.linalg.norm(w_T)))
+    return {"value": round(n / t_total, 3), "unit": "frame-pairs/s", "cores": 1, "kind": "reference",
+            "cv2_version": getattr(cv2, "__version__", "?"), "cv2_threads_before": threads,
+            "sample": f"{n} of the one-thread sample's pairs; cv2.BFMatcher(NORM_HAMMING2, crossCheck=True) + cv2.solvePnP "
+                      f"(AP3P, ITERATIVE) + cv2.Rodrigues inside the reference's loop structure",
+            "gpu_vs_cv2": {"tracked_sets_equal": f"{eq_kp}/{n}", "supporter_masks_equal": f"{eq_mask}/{n}",
+                           "worst_pose_rel_err": float(f"{worst:.3e}")}}
 
 
 def _warm(_):

@@ -23,7 +23,8 @@ def _standin(mutual=False):
 
         def match(self, q, t):
             assert self.cross
-            return list(orc.to_dmatches(*(orc.bf_match_mutual if mutual else orc.bf_match)(q, t, self.norm)))
+            rule = orc.crosscheck_mutual_from_matrix if mutual else orc.crosscheck_from_matrix    # not orc.bf_match: bench rebinds it
+            return list(orc.to_dmatches(*rule(orc.hamming_matrix(q, t, self.norm))))
 
         def knnMatch(self, q, t, k):
             idx, dist = orc.knn2_from_matrix(orc.hamming_matrix(q, t, self.norm))
@@ -71,3 +72,26 @@ def test_oracle_against_the_installed_cv2():
 def test_hip_path_against_the_installed_cv2():
     cv2 = pytest.importorskip("cv2")
     _check(cv2, cv2_pin.HipSubject())
+
+
+def test_bench_cv2_leg_runs_the_reference_loop_on_the_given_cv2():
+    """bench.py's optional `cpu_baseline.cv2_reference_path` (only where cv2 imports): the oracle's per-pair driver with
+    BFMatcher / solvePnP / Rodrigues bound to the cv2 module it is given.  With the stand-in the result must be the plain
+    oracle's, and the port's own bindings must be back afterwards."""
+    import bench
+    from slam_amd.synth import SynthConfig, SynthSequence
+    cfg = SynthConfig(n_frames=12, n_features=260, seed=3, spawn_per_frame=30, ragged=7)
+    desc, xy, count = SynthSequence(cfg).frames(0, 3)
+
+    def frame(i):
+        n0, n1 = count[i]
+        return dict(dsc_l=desc[i, 0, :n0, :61], dsc_r=desc[i, 1, :n1, :61], xy_l=xy[i, 0, :n0], xy_r=xy[i, 1, :n1])
+
+    for p in range(2):
+        _, it_a, kp_a, mask_a, T_a = bench._oracle_pair((frame(p), frame(p + 1), 1000 + p))
+        _, it_b, kp_b, mask_b, T_b = bench._oracle_pair((frame(p), frame(p + 1), 1000 + p), cv2=_standin())
+        assert len(kp_a) > 50 and it_a == it_b and np.array_equal(kp_a, kp_b) and np.array_equal(mask_a, mask_b)
+        assert np.array_equal(T_a, T_b)
+    o = bench._oracle()
+    assert o.pnp is o._port_pnp and o.bf_match.__name__ == "<lambda>"
+    assert bench._try_cv2() is None or hasattr(bench._try_cv2(), "BFMatcher")
