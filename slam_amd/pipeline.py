@@ -59,6 +59,8 @@ class ShardTracker:
     VALU-bound matching of the next.  Results are identical to n_chunks = 1: every pair's computation is independent
     of which block carries it."""
 
+    MAX_PAIRS_PER_CALL = 65535      # slam_track_pairs' limit; run() hands longer pair lists over in blocks of this size
+
     def __init__(self, n_frames: int, n_pairs: int, n_max: int, cfg: HotPathConfig | None = None, n_chunks: int = 1,
                  taper: float = 1.0):
         self.cfg = cfg or HotPathConfig()
@@ -70,8 +72,9 @@ class ShardTracker:
         self._c.pipeline_chunks = max(1, int(n_chunks))
         self._c.pipeline_taper_permille = int(round(1000 * taper))     # each chunk = taper x the previous one
         L = _lib.lib()
-        self.d_ws_bytes = L.slam_track_device_workspace_bytes(n_frames, n_pairs, n_max, ctypes.byref(self._c))
-        self.h_ws_bytes = L.slam_track_host_workspace_bytes(n_frames, n_pairs, n_max, ctypes.byref(self._c))
+        per_call = min(n_pairs, self.MAX_PAIRS_PER_CALL)          # the workspaces serve one call (one block) at a time
+        self.d_ws_bytes = L.slam_track_device_workspace_bytes(n_frames, per_call, n_max, ctypes.byref(self._c))
+        self.h_ws_bytes = L.slam_track_host_workspace_bytes(n_frames, per_call, n_max, ctypes.byref(self._c))
         self.d_ws = torch.empty(self.d_ws_bytes, dtype=torch.uint8, device=self.dev)
         self.h_ws = torch.empty(self.h_ws_bytes, dtype=torch.uint8).pin_memory()
         self.tracked_kp = torch.zeros((n_pairs, n_max, 4), dtype=torch.int32, device=self.dev)
@@ -90,19 +93,35 @@ class ShardTracker:
         f0 = np.ascontiguousarray(pair_f0, dtype=np.int32)
         f1 = np.ascontiguousarray(pair_f1, dtype=np.int32)
         sd = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64) & 0xFFFFFFFF, dtype=np.uint32)
-        io = _lib.SlamTrackIO()
-        io.d_desc, io.d_xy, io.d_count = ops._dev(desc, torch.uint8), ops._dev(xy, torch.float32), ops._dev(count, torch.int32)
-        io.n_frames, io.n_max = F, self.n_max
-        io.h_pair_f0, io.h_pair_f1, io.h_pair_seed = f0.ctypes.data, f1.ctypes.data, sd.ctypes.data
-        io.n_pairs = P
-        io.d_tracked_kp = self.tracked_kp.data_ptr()
-        io.h_pose, io.h_stats, io.h_mask = self.h_pose.data_ptr(), self.h_stats.data_ptr(), self.h_mask.data_ptr()
-        io.d_workspace, io.d_workspace_bytes = self.d_ws.data_ptr(), self.d_ws_bytes
-        io.h_workspace, io.h_workspace_bytes = self.h_ws.data_ptr(), self.h_ws_bytes
+        d_desc, d_xy, d_count = desc, xy, count
+        ops._dev(d_desc, torch.uint8), ops._dev(d_xy, torch.float32), ops._dev(d_count, torch.int32)     # device / dtype / layout checks
         L = _lib.lib()
-        _lib.check(L.slam_track_pairs(ctypes.byref(self._c), ctypes.byref(io), ops._stream()))
         tm = np.zeros(8)
-        L.slam_track_last_timing(tm.ctypes.data)
+        M = self.MAX_PAIRS_PER_CALL
+        for a in range(0, max(P, 1), M):
+            e = min(a + M, P)
+            # one call when the list fits (every frame handed over, as before); otherwise block by block, each with
+            # the frame range its pairs touch, indices rebased to it
+            lo, hi = (0, F) if P <= M else (int(min(f0[a:e].min(), f1[a:e].min())), int(max(f0[a:e].max(), f1[a:e].max())) + 1)
+            f0b, f1b = np.ascontiguousarray(f0[a:e] - lo), np.ascontiguousarray(f1[a:e] - lo)
+            sdb = np.ascontiguousarray(sd[a:e])
+            io = _lib.SlamTrackIO()
+            io.d_desc = d_desc.data_ptr() + 2 * lo * self.n_max * 64
+            io.d_xy = d_xy.data_ptr() + 2 * lo * self.n_max * 8
+            io.d_count = d_count.data_ptr() + 2 * lo * 4
+            io.n_frames, io.n_max = hi - lo, self.n_max
+            io.h_pair_f0, io.h_pair_f1, io.h_pair_seed = f0b.ctypes.data, f1b.ctypes.data, sdb.ctypes.data
+            io.n_pairs = e - a
+            io.d_tracked_kp = self.tracked_kp.data_ptr() + a * self.n_max * 16
+            io.h_pose = self.h_pose.data_ptr() + a * 96
+            io.h_stats = self.h_stats.data_ptr() + a * 32
+            io.h_mask = self.h_mask.data_ptr() + a * (self.n_max // 64) * 8
+            io.d_workspace, io.d_workspace_bytes = self.d_ws.data_ptr(), self.d_ws_bytes
+            io.h_workspace, io.h_workspace_bytes = self.h_ws.data_ptr(), self.h_ws_bytes
+            _lib.check(L.slam_track_pairs(ctypes.byref(self._c), ctypes.byref(io), ops._stream()))
+            t1 = np.zeros(8)
+            L.slam_track_last_timing(t1.ctypes.data)
+            tm += t1
         pose = self.h_pose[:P].numpy().reshape(P, 3, 4).copy()
         stats = self.h_stats[:P].numpy().copy()
         if unpack_mask:

@@ -279,6 +279,33 @@ def test_results_do_not_depend_on_chunk_plan():
         assert np.array_equal(res.tracked_kp.cpu().numpy(), base.tracked_kp.cpu().numpy()), (chunks, taper)
 
 
+def test_pair_lists_beyond_one_call_are_run_in_blocks(monkeypatch):
+    """slam_track_pairs takes at most 65 535 pairs; ShardTracker.run hands a longer list over block by block, each with
+    the frame range its pairs touch.  With the block size turned down to 7 the result equals the one-call result, for
+    consecutive pairs and for a loop-closure-like list (far-apart and repeated frames), with and without chunks."""
+    F = 24
+    cfg = SynthConfig(n_frames=F, n_features=420, seed=5, ragged=True)
+    desc, xy, count = SynthSequence(cfg).frames(0, F)
+    n_max = cfg.n_max
+    args = (dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)))
+    c0, c1 = consecutive_pairs(F)
+    rng = np.random.default_rng(9)
+    lists = [(c0, c1), (rng.integers(0, F, 31).astype(np.int32), rng.integers(0, F, 31).astype(np.int32))]
+    for f0, f1 in lists:
+        seeds = 300 + np.arange(len(f0))
+        base = ShardTracker(F, len(f0), n_max).run(*args, f0, f1, seeds)
+        for chunks in (1, 2):
+            with monkeypatch.context() as m:
+                m.setattr(ShardTracker, "MAX_PAIRS_PER_CALL", 7)
+                trk = ShardTracker(F, len(f0), n_max, n_chunks=chunks)
+                res = trk.run(*args, f0, f1, seeds)
+            assert trk.d_ws_bytes < ShardTracker(F, len(f0), n_max, n_chunks=chunks).d_ws_bytes      # sized for one block
+            assert res.timing_ms[7] >= -(-len(f0) // 7)                                              # one or more launches per block
+            assert np.array_equal(res.pose, base.pose, equal_nan=True) and np.array_equal(res.mask, base.mask)
+            assert np.array_equal(res.stats[:, :6], base.stats[:, :6])
+            assert np.array_equal(res.tracked_kp.cpu().numpy(), base.tracked_kp.cpu().numpy())
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_frame_range_shards_reproduce_the_whole_movie(world):
     """BASELINE configs[2]: the ranks' blocks (slam_amd.dist.shard_frames: pairs [a, b) + one halo frame), run one
