@@ -306,6 +306,26 @@ def test_pair_lists_beyond_one_call_are_run_in_blocks(monkeypatch):
             assert np.array_equal(res.tracked_kp.cpu().numpy(), base.tracked_kp.cpu().numpy())
 
 
+def test_seventy_thousand_pairs_in_one_run():
+    """The real limit: 70 000 loop-closure-like pairs over a 40-frame sequence of small images go through in two
+    blocks; a sample of them equals the same pairs run on their own."""
+    F, P = 40, 70000
+    cfg = SynthConfig(n_frames=F, n_features=60, seed=2, spawn_per_frame=10, ragged=5)
+    desc, xy, count = SynthSequence(cfg).frames(0, F)
+    n_max = cfg.n_max
+    args = (dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)))
+    rng = np.random.default_rng(1)
+    f0 = rng.integers(0, F, P).astype(np.int32)
+    f1 = np.clip(f0 + rng.integers(-2, 3, P), 0, F - 1).astype(np.int32)
+    seeds = 5 + np.arange(P)
+    res = ShardTracker(F, P, n_max).run(*args, f0, f1, seeds)
+    assert res.timing_ms[7] >= 2 and (res.stats[:, 5] != 0).all()                 # every pair has a status: none was skipped
+    pick = np.concatenate([np.arange(0, 40), np.arange(65515, 65555), np.arange(P - 40, P)])
+    sub = ShardTracker(F, len(pick), n_max).run(*args, f0[pick], f1[pick], seeds[pick])
+    assert np.array_equal(res.stats[pick, :6], sub.stats[:, :6]) and np.array_equal(res.mask[pick], sub.mask)
+    assert np.array_equal(res.pose[pick], sub.pose, equal_nan=True) and (sub.stats[:, 5] & _lib.SLAM_PAIR_OK).sum() > 60
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_frame_range_shards_reproduce_the_whole_movie(world):
     """BASELINE configs[2]: the ranks' blocks (slam_amd.dist.shard_frames: pairs [a, b) + one halo frame), run one
