@@ -14,7 +14,8 @@ figure (every rank its own 3450-frame range of a longer drive) is measured in th
 under "weak".  `python bench.py --gpus N` with N > 1 starts the N ranks itself (one process per GPU through
 torch.distributed.run); under an external launcher (RANK set) it is one of the ranks.  Rank 0 prints ONE JSON line.
 
---config stress / loops time BASELINE configs[3] / configs[4] with the same JSON schema (one GPU).
+--config stress / loops time BASELINE configs[3] / configs[4] with the same JSON schema; loops also takes --gpus N
+(the one candidate-pair list block-partitioned over the ranks, strong scaling).
 """
 from __future__ import annotations
 
@@ -41,10 +42,16 @@ HBM_PEAK_GBPS = 8000.0
 # costs 8 x (1 + 1 + 2) + 1 = 33 full-rate issue slots.
 EXEC_OPS_PER_PAIR = 25
 ISSUE_SLOTS_PER_PAIR = 33
-VALU_SUSTAINED_TSLOTS = 62.0      # measured: v_xor / v_bitop3 / v_add sustained, profiles/r1_valu_peak_microbench.txt
+# Sustained issue rates measured on this part (tools/valu_peak.hip -> profiles/r1_valu_peak_microbench.txt, 40 launches
+# back to back, T lane-ops/s): the fastest full-rate instruction is the ceiling a "fraction of issue slots" is quoted
+# against (so that it cannot exceed 1), and the three rates together give the ceiling of the matcher's own mix.
+VALU_SUSTAINED_TSLOTS = 66.27     # v_xor_b32
+VALU_SUSTAINED_BITOP3, VALU_SUSTAINED_BCNT = 61.09, 36.37
+# descriptor pairs/s if every instruction of a pair issued at its own measured sustained rate: 8 xor + 1 cmp, 8 bitop3, 8 bcnt
+MIX_CEILING_TPAIRS = 1.0 / (9 / VALU_SUSTAINED_TSLOTS + 8 / VALU_SUSTAINED_BITOP3 + 8 / VALU_SUSTAINED_BCNT)
 SURVEY_OPS_PER_PAIR = 80
-PMC_SUMMARY = os.path.join("profiles", "r2_pmc_summary.json")
-PMC_SUMMARY_FALLBACK = os.path.join("profiles", "r1_final_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r3_pmc_summary.json")
+PMC_SUMMARY_FALLBACK = os.path.join("profiles", "r2_pmc_summary.json")
 
 
 def parse(argv=None):
@@ -264,6 +271,9 @@ def matcher_roofline(args, leg):
         "issue_slot_rate_Tslots": round(slots, 3),
         "issue_slot_frac_of_nominal_peak": round(slots / VALU_PEAK_TLANEOPS, 4),
         "issue_slot_frac_of_measured_sustained": round(slots / VALU_SUSTAINED_TSLOTS, 4),
+        "descriptor_pairs_Tps": round(desc_pairs / (m_ms * 1e-3) / 1e12, 4),
+        "measured_instruction_mix_ceiling_Tpairs": round(MIX_CEILING_TPAIRS, 4),
+        "frac_of_measured_instruction_mix_ceiling": round(desc_pairs / (m_ms * 1e-3) / 1e12 / MIX_CEILING_TPAIRS, 4),
         "achieved_survey_units": round(desc_pairs * SURVEY_OPS_PER_PAIR / (m_ms * 1e-3) / 1e12, 3),
         "descriptor_pairs_per_step": desc_pairs, "kernel_ms_per_step": round(m_ms, 4),
         "hbm_algorithmic_bytes_per_step": alg_bytes,
@@ -695,52 +705,96 @@ def run_stress(args, rk: Rank):
 
 
 def run_loops(args, rk: Rank):
-    """BASELINE configs[4]: loop-closure candidate validation, 3450 frames x 5 candidates each, one device pass."""
+    """BASELINE configs[4]: loop-closure candidate validation, 3450 frames x 5 candidates each.  N = 1: one device pass.
+    N > 1 (north_star: "Loop-closure candidate consensus matching ... shards the same way"): the ONE flat list of
+    (candidate, current) pairs block-partitioned over the ranks (slam_amd.dist.shard_list); a rank holds, stereo-matches
+    and tracks only the frames its block touches, no data-path collective, one all-gather of the 128-byte pose +
+    counter rows (strong scaling: `value` = all pairs / max-over-ranks time)."""
     torch = rk.torch
+    from slam_amd import dist as sdist
     from slam_amd import pipeline
     from slam_amd.synth import SynthConfig, SynthSequence, loop_candidate_pairs
     F = args.frames
     scfg = SynthConfig(n_frames=F, n_features=args.features, seed=args.seed)
-    desc, xy, count = SynthSequence(scfg).frames(0, F)
     n_max = scfg.n_max
-    f0, f1 = loop_candidate_pairs(F)
-    P = len(f0)
-    trk = pipeline.ShardTracker(F, P, n_max, hot_path_config(args), n_chunks=1)
-    dev_args = (torch.from_numpy(desc.reshape(2 * F, n_max, 64)).cuda(), torch.from_numpy(xy.reshape(2 * F, n_max, 2)).cuda(),
-                torch.from_numpy(count.reshape(2 * F)).cuda())
-    seeds = 9000 + np.arange(P)
-    res, elapsed, tm = _timed_passes(rk, trk, dev_args, f0, f1, seeds, args)
+    g0, g1 = loop_candidate_pairs(F)                                        # movie frame indices
+    P_total = len(g0)
+    a, b = sdist.shard_list(P_total, rk.rank, rk.world)
+    used, f0, f1 = sdist.frames_of_block(g0, g1, a, b)
+    seq = SynthSequence(scfg)
+    t0 = time.time()
+    Fl = len(used)
+    desc = np.zeros((max(Fl, 1), 2, n_max, 64), np.uint8)
+    xy = np.zeros((max(Fl, 1), 2, n_max, 2), np.float32)
+    count = np.zeros((max(Fl, 1), 2), np.int32)
+    if Fl == F:
+        desc, xy, count = seq.frames(0, F)
+    else:
+        for k, f in enumerate(used):                                        # every frame is a pure function of its index
+            fr = seq.frame(int(f))
+            desc[k], xy[k], count[k] = fr["desc"], fr["xy"], fr["count"]
+    gen_s = time.time() - t0
+    P = b - a
+    Fd = len(count)
+    trk = pipeline.ShardTracker(Fd, max(P, 1), n_max, hot_path_config(args), n_chunks=1)
+    dev_args = (torch.from_numpy(desc.reshape(2 * Fd, n_max, 64)).cuda(), torch.from_numpy(xy.reshape(2 * Fd, n_max, 2)).cuda(),
+                torch.from_numpy(count.reshape(2 * Fd)).cuda())
+    seeds = 9000 + a + np.arange(P)                                         # a pair's seed is its index in the whole list
+
+    def step():
+        res = trk.run(*dev_args, f0, f1, seeds, unpack_mask=False)
+        pose, stats = sdist.gather_shard_results(res.pose, res.stats, P_total)
+        return res, stats
+
+    for _ in range(args.warmup):
+        step()
+    rk.fence()
+    t0, tm = time.perf_counter(), []
+    for _ in range(args.steps):
+        res, stats = step()
+        tm.append(res.timing_ms.copy())
+    rk.fence()
+    elapsed = rk.max_over_ranks(time.perf_counter() - t0)
+    frames_per_rank = rk.max_over_ranks(float(Fl))
     if rk.rank != 0:
         return
-    perc = res.inliers_percentage()
-    near = np.arange(P) % 5 < 2
+    T = np.maximum(stats[:, 0], 1)
+    perc = 100.0 * stats[:, 1] / T
+    near = np.arange(P_total) % 5 < 2
     cnt = count.astype(np.int64)
-    desc_pairs = int((cnt[:, 0] * cnt[:, 1]).sum() + (cnt[f0, 0] * cnt[f1, 0]).sum())
+    desc_pairs = int((cnt[:Fl, 0] * cnt[:Fl, 1]).sum() + (cnt[f0, 0] * cnt[f1, 0]).sum())
     st = stage_dict(tm)
     exec_rate = desc_pairs * EXEC_OPS_PER_PAIR / (st["match"] * 1e-3) / 1e12
-    out = {"metric": "frame-pairs/sec (match+triangulate+PnP-RANSAC)", "value": round(P * args.steps / elapsed, 2),
-           "unit": "frame-pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+    world = rk.world
+    where = "one device pass" if world == 1 else (f"the ONE pair list block-partitioned over {world} GPUs, each rank holding only the "
+                                                  f"frames its block touches (at most {int(frames_per_rank)} of {F})")
+    out = {"metric": "frame-pairs/sec (match+triangulate+PnP-RANSAC)", "value": round(P_total * args.steps / elapsed, 2),
+           "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+           "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
            "dtype": "u32 popcount + f64", "data": "synthetic",
            "config": {"workload": f"loop-closure candidate validation (BASELINE configs[4]): {F} frames x {args.features} features/image, "
-                                  f"every frame against 5 candidates (2 revisits + 3 earlier frames); {P} candidate pairs per step",
+                                  f"every frame against 5 candidates (2 revisits + 3 earlier frames); {P_total} candidate pairs per step, {where}",
                       "norm": "NORM_HAMMING2", "match": "cross-check brute force", "ransac": "adaptive (prob 0.9999, cap 1000)",
-                      "acceptance": "inliers % > 85 (PoseGraph.py:24)"},
+                      "acceptance": "inliers % > 85 (PoseGraph.py:24)", "parallelism": f"pair-list x{world}"},
            "roofline": {"kernel": "allpairs_top2_kernel", "bound": "valu", "unit": "Tlaneop/s", "achieved": round(exec_rate, 3),
                         "peak": round(VALU_PEAK_TLANEOPS, 2), "frac": round(exec_rate / VALU_PEAK_TLANEOPS, 4),
                         "descriptor_pairs_per_step": desc_pairs, "kernel_ms_per_step": st["match"], "traffic": None},
            "stage_ms": st,
            "quality": {"revisits_over_85pct": round(float((perc[near] > 85).mean()), 4),
                        "others_over_85pct": round(float((perc[~near] > 85).mean()), 4),
-                       "mean_iterations": round(float(res.stats[:, 2].mean()), 1), "pairs": P}}
+                       "mean_iterations": round(float(stats[:, 2].mean()), 1), "pairs": P_total},
+           "setup_s": {"synthetic_generation": round(gen_s, 2)}}
+    if world > 1:
+        out["roofline"]["note"] = "rank 0's launches (its block of the pair list)"
     rk.emit(out)
 
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
-    if args.config != "trajectory" and args.gpus != 1:
-        raise SystemExit("--config stress / loops are one-GPU configurations")
+    if args.config == "stress" and args.gpus != 1:
+        raise SystemExit("--config stress is a one-GPU configuration")
     if args.gpus > 1 and "RANK" not in os.environ:
         return self_launch(args, argv)                                     # before anything touches the GPU
     if not args.frames:

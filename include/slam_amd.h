@@ -58,6 +58,12 @@ extern "C" {
 
 const char *slam_version(void);
 const char *slam_last_error_string(void);
+/* Explicit teardown (no counterpart in the reference, which owns no threads and no device objects): stops and joins the
+ * library's host worker pool and releases the calling thread's internal streams / events while the HIP runtime is still
+ * up.  Optional -- nothing in the library joins threads or calls HIP from a static destructor -- and idempotent; the
+ * library stays usable afterwards (host-side steps then run on the calling thread only).  slam_amd/_lib.py calls it
+ * from a Python atexit hook, i.e. before any library's exit handlers run. */
+int slam_shutdown(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Matching.  Replaces cv2.BFMatcher(NORM_HAMMING2, crossCheck=True).match (utils/utills.py:57-70,

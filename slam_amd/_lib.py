@@ -5,6 +5,7 @@ compute entry point needs a HIP device.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes
 import os
 
@@ -50,6 +51,7 @@ class SlamTrackIO(ctypes.Structure):
 SIGNATURES = {
     "slam_version": (ctypes.c_char_p, []),
     "slam_last_error_string": (ctypes.c_char_p, []),
+    "slam_shutdown": (c_int, []),
     "slam_match_workspace_bytes": (c_size_t, [c_int, c_int]),
     "slam_match_hamming": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                    c_size_t, c_void_p]),
@@ -110,7 +112,16 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = L
+        # Explicit shutdown BEFORE interpreter / library finalisation: joins the host worker pool and releases the main
+        # thread's streams and events while the HIP runtime (and a profiler's tool library, if one is attached) is
+        # still up, so nothing of this library is left for process-exit handlers to trip over.
+        atexit.register(_shutdown)
     return _lib
+
+
+def _shutdown():
+    if _lib is not None:
+        _lib.slam_shutdown()
 
 
 def check(code):

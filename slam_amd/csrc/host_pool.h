@@ -12,6 +12,7 @@
 //
 // Plain C++ (no HIP): tests/host_pool_stress.cpp builds this header with -fsanitize=thread.
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <exception>
@@ -22,9 +23,14 @@
 
 class HostPool {
 public:
+    // The process-wide pool is created on first use and NEVER destroyed: a static destructor would join the workers
+    // from inside library finalisation (__cxa_finalize), after other libraries -- the HIP runtime, a profiler's tool
+    // library -- may already be gone and while their own exit handlers run.  Callers that want the threads stopped
+    // before the process ends call shutdown() (slam_shutdown(); slam_amd/_lib.py does, from a Python atexit hook);
+    // otherwise the workers stay parked on `cv_work`, which then outlives them, until the process exits.
     static HostPool &get() {
-        static HostPool pool(default_threads());
-        return pool;
+        static HostPool *pool = new HostPool(default_threads());
+        return *pool;
     }
     explicit HostPool(int n_threads) {
         try {
@@ -32,15 +38,23 @@ public:
         } catch (...) {
             // the system refused another thread: the pool works with those it has (the caller is always one of them)
         }
+        n_workers = (int)threads.size() + 1;
     }
-    ~HostPool() {
+    ~HostPool() { shutdown(); }      // pools with automatic storage (tests); the process-wide one is never destroyed
+    // Stops and joins the workers (waiting for a job in flight first).  Idempotent.  The pool stays usable: run() then
+    // executes every chunk on the calling thread.
+    void shutdown() {
+        std::lock_guard<std::mutex> serial(gate);
         {
             std::lock_guard<std::mutex> lk(m);
+            if (stop) return;
             stop = true;
             ++generation;
         }
         cv_work.notify_all();
+        n_workers = 1;
         for (auto &t : threads) t.join();
+        threads.clear();
     }
     HostPool(const HostPool &) = delete;
     HostPool &operator=(const HostPool &) = delete;
@@ -74,7 +88,7 @@ public:
         }
         if (failed) std::rethrow_exception(failed);
     }
-    int workers() const { return (int)threads.size() + 1; }
+    int workers() const { return n_workers.load(std::memory_order_relaxed); }
 
     // Threads per process: the host's cores shared between the ranks of this node (torchrun exports LOCAL_WORLD_SIZE),
     // at most 16 (a one-GPU box's CPU share); SLAM_HOST_THREADS overrides.
@@ -127,6 +141,7 @@ private:
         }
     }
     std::vector<std::thread> threads;
+    std::atomic<int> n_workers{1};
     std::mutex gate, m;
     std::condition_variable cv_work, cv_done;
     const std::function<void(int)> *fn = nullptr;

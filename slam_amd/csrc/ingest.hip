@@ -17,7 +17,7 @@ __device__ __forceinline__ int usable_rows(const int64_t *row_ptr, const int *co
     const long a = row_ptr[img];
     int n = count[img];
     n = n < 0 ? 0 : (n > n_max ? n_max : n);
-    if (a < 0 || a + n > n_rows_total) n = 0;
+    if (a < 0 || a > n_rows_total - n) n = 0;      // not `a + n > total`: a hostile row pointer near INT64_MAX would wrap
     return n;
 }
 

@@ -563,11 +563,15 @@ constexpr long PLAN_TARGET_WORKGROUPS = 7000;
 
 GridPlan plan_grid(int n_prob, int a_rows, int b_rows) {
     const int tiles_b = std::max(1, slam_div_up(b_rows, TILE_B));
-    if (const char *e = std::getenv("SLAM_MATCH_PLAN")) {             // "rows,nsplit": tuning runs only (tools/sweep_grid_plan.py)
+#ifdef SLAM_MATCH_ALL_ROW_VARIANTS
+    // tuning builds only (tools/sweep_grid_plan.py builds with every row variant): "rows,nsplit" from the environment.
+    // The shipped library has one row variant and reads no environment variable here.
+    if (const char *e = std::getenv("SLAM_MATCH_PLAN")) {
         int r = 0, ns = 0;
         if (std::sscanf(e, "%d,%d", &r, &ns) == 2 && r >= 1 && r <= 4 && ns >= 1)
             return {r, std::min(std::min(ns, MAX_SPLIT), tiles_b)};
     }
+#endif
     const long tiles_a = (long)slam_div_up(a_rows, TILE_A) * (n_prob > 0 ? n_prob : 1);
     long ns = (PLAN_TARGET_WORKGROUPS + tiles_a - 1) / tiles_a;
     ns = std::min<long>(ns, std::min(tiles_b, 16));

@@ -529,6 +529,13 @@ struct ThreadState {
         }
         device = -1;
     }
+    // drops the handles without destroying them (their device is unreachable)
+    void forget() {
+        for (Lane &ln : lane) ln.ev_ready = false;
+        fork = base = nullptr;
+        for (auto &s : side_stream) s = nullptr;
+        device = -1;
+    }
     ~ThreadState() {
         if ((long)syscall(SYS_gettid) == (long)getpid()) return;      // main thread at process exit
         int cur = -1;
@@ -545,8 +552,10 @@ int bind_device() {
     SLAM_HIP_CHECK(hipGetDevice(&dev));
     if (dev == g_ts.device) return SLAM_OK;
     if (g_ts.device >= 0) {
-        // objects of the previous device are destroyed with that device current
+        // objects of the previous device are destroyed with that device current; if that device cannot be made current
+        // any more its handles are forgotten, not reused: the new device gets a fresh set either way
         if (hipSetDevice(g_ts.device) == hipSuccess) g_ts.release();
+        else g_ts.forget();
         SLAM_HIP_CHECK(hipSetDevice(dev));
     }
     g_ts.device = dev;
@@ -621,6 +630,26 @@ extern "C" size_t slam_track_device_workspace_bytes(int n_frames, int n_pairs, i
 extern "C" size_t slam_track_host_workspace_bytes(int n_frames, int n_pairs, int n_max, const SlamTrackConfig *cfg) {
     return workspace_bytes(n_frames, n_pairs, n_max, cfg, true);
 }
+
+// Explicit teardown, for callers that want it done at a moment of their choosing instead of during process exit:
+// stops and joins the host worker pool and releases the CALLING thread's streams / events while the HIP runtime is
+// still up.  Nothing in this library joins threads or calls HIP from a static destructor (host_pool.h, ThreadState), so
+// skipping the call is safe; making it leaves no thread and no HIP object of this library behind when the exit
+// handlers of other libraries (the HIP runtime, a profiler's tool library) run.  The library stays usable afterwards
+// (host steps then run on the calling thread only).
+extern "C" int slam_shutdown(void) try {
+    if (g_ts.device >= 0) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess) {
+            if (cur == g_ts.device || hipSetDevice(g_ts.device) == hipSuccess) g_ts.release();
+            if (cur != g_ts.device && cur >= 0) (void)hipSetDevice(cur);
+        }
+        g_ts.device = -1;
+    }
+    HostPool::get().shutdown();
+    return SLAM_OK;
+}
+SLAM_CATCH_ALL("slam_shutdown")
 
 extern "C" int slam_track_last_timing(double *h_ms8) {
     if (!h_ms8) return SLAM_E_INVALID;

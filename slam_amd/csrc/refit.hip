@@ -1,5 +1,5 @@
-// PnP refit on the supporters: Levenberg-Marquardt on the left-image reprojection error, one wavefront per
-// frame pair (four when the launch is too small to fill the chip).
+// PnP refit on the supporters: Levenberg-Marquardt on the left-image reprojection error, one workgroup of four
+// wavefronts per frame pair.
 //
 // Replaces extra_refine -> pnp(world[mask], left1[mask], K, cv2.SOLVEPNP_ITERATIVE) (utils/utills.py:548-571,
 // :585-596).  cv2's ITERATIVE solver is a DLT initialisation followed by Levenberg-Marquardt (CvLevMarq, at
@@ -114,12 +114,10 @@ constexpr int MAX_EVAL = 60;
 #endif
 
 // Wavefronts per pair (RW).  A pair's solve is one long dependent chain (passes over the supporters, 27 butterfly
-// reductions, a serial 6x6 Cholesky, the pose update): ~100 us whatever the launch.  A whole shard hides that behind
-// other pairs (three per CU by LDS, 4.5 rounds: 0.41 ms) and splitting a pair over four wavefronts only adds
-// instructions there (0.47 ms).  A launch that does not fill the chip -- a loop-closure call with a handful of
-// candidates, a rank's share of a strongly scaled movie, the 8k-feature configuration's 30 pairs -- is all latency:
-// then the passes over the points are split over four wavefronts, the scalar part (reduced sums -> step -> new pose)
-// being computed redundantly by every thread from the same bits, so control flow stays uniform over the workgroup.
+// reductions, a serial 6x6 Cholesky, the pose update): ~100 us with one wavefront whatever the launch.  The passes over
+// the points are split over RW wavefronts, the scalar part (reduced sums -> step -> new pose) being computed
+// redundantly by every thread from the same bits, so control flow stays uniform over the workgroup.  RW is a
+// compile-time constant of the library (SLAM_REFIT_WAVES below), never a function of the launch.
 //
 // LDS: the supporters of the pair, compacted once (x, y, z as doubles + the left observation in its own type: 32 bytes per
 // supporter for float32 key-point rows), when there are at most `cap` of them; every Levenberg-Marquardt pass then reads them from LDS with all
@@ -361,15 +359,22 @@ __global__ __launch_bounds__(RW * 64) void refit_kernel(Mat33 K, const double *X
     }
 }
 
-// supporters per pair held in LDS (32 bytes each).  Many pairs: 1536 (48 KB, three pairs per CU keep the launch's
-// occupancy); few pairs (the stress configuration's 8k-feature images): up to 4096 (128 KB), occupancy being no concern
+// A pair's pose must not depend on the launch it is part of: slam_track_pairs refits once per chunk, rank block or
+// 65535-pair block, and the shard / chunk / multi-GPU paths promise results bit-identical to one whole-shard call.  The
+// sums' order is fixed by (wavefronts per pair, LDS path or global walk), so both are functions of the pair's own
+// layout only -- never of n_seg.  (Round 2 chose 4 wavefronts below 768 pairs and 1 above, and a larger LDS capacity
+// below 256 pairs: the same pair got different pose bits at --chunks >= 5 or on 8 ranks than in the one-GPU run.)
+//
+// Wavefronts per pair: 4.  On a whole shard one wavefront per pair is ~15 % faster (0.41 against 0.47 ms of a 15.5 ms
+// step); four shorten the dependent chain where the launch does not fill the chip (a rank's share of a strongly scaled
+// movie, a loop-closure call, the 8k-feature configuration), which is where the refit is exposed.
+#ifndef SLAM_REFIT_WAVES
+#define SLAM_REFIT_WAVES 4
+#endif
+// supporters per pair held in LDS (32 bytes each with float32 observations): rows of up to 2048 key-points keep 1536
+// (48 KB, three pairs per CU); longer rows (the 8k-feature configuration) up to 4096 (128 KB, one pair per CU)
 #ifndef SLAM_REFIT_CAP
 #define SLAM_REFIT_CAP 1536
-#endif
-// launches smaller than this many pairs run four wavefronts per pair (see RW above): below it the 256 CUs are not
-// filled by one-wavefront workgroups three to a CU
-#ifndef SLAM_REFIT_WIDE_BELOW
-#define SLAM_REFIT_WIDE_BELOW 768
 #endif
 
 template <typename XY4, int RW>
@@ -377,7 +382,7 @@ int launch_refit_rw(const Mat33 &K, const double *d_X, const XY4 *d_xy1, const i
                     const uint64_t *d_mask_words, const double *d_pose0, double *d_pose, uint8_t *d_status, hipStream_t st) {
     const size_t per = 24 + 2 * sizeof(decltype(XY4::x));       // LDS bytes per supporter
     constexpr size_t LDS_DEFAULT = 60 * 1024, LDS_RAISED = 158 * 1024;   // dynamic part; the kernel's static arrays take < 1 KB of the 64 / 160 KB
-    int cap = std::min(seg_stride, n_seg <= 256 ? 4096 : SLAM_REFIT_CAP);
+    int cap = std::min(seg_stride, seg_stride <= 2048 ? SLAM_REFIT_CAP : 4096);
     cap = std::min(cap, (int)(LDS_RAISED / per));
     size_t lds_bytes = (size_t)cap * per;
     if (lds_bytes > LDS_DEFAULT) {
@@ -403,9 +408,7 @@ int launch_refit_rw(const Mat33 &K, const double *d_X, const XY4 *d_xy1, const i
 template <typename XY4>
 int launch_refit_t(const Mat33 &K, const double *d_X, const XY4 *d_xy1, const int32_t *d_count, int n_seg, int seg_stride,
                    const uint64_t *d_mask_words, const double *d_pose0, double *d_pose, uint8_t *d_status, hipStream_t st) {
-    if (n_seg < SLAM_REFIT_WIDE_BELOW)
-        return launch_refit_rw<XY4, 4>(K, d_X, d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status, st);
-    return launch_refit_rw<XY4, 1>(K, d_X, d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status, st);
+    return launch_refit_rw<XY4, SLAM_REFIT_WAVES>(K, d_X, d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status, st);
 }
 
 }  // namespace

@@ -148,6 +148,44 @@ def gather_frames(local_frames: np.ndarray, n_frames: int, device=None) -> np.nd
     return torch.cat([body, last]).cpu().numpy()
 
 
+def frames_of_block(pair_f0: np.ndarray, pair_f1: np.ndarray, a: int, b: int):
+    """The frames a block [a, b) of a flat (frame 0, frame 1) pair list touches, ascending, and the block's two index
+    arrays rebased to positions in that list: what a rank reads, stereo-matches and tracks for its block."""
+    f0 = np.asarray(pair_f0[a:b], dtype=np.int64)
+    f1 = np.asarray(pair_f1[a:b], dtype=np.int64)
+    used = np.unique(np.concatenate([f0, f1]))
+    return used, np.searchsorted(used, f0).astype(np.int32), np.searchsorted(used, f1).astype(np.int32)
+
+
+def track_pairs_sharded(pair_f0, pair_f1, seeds, run_block, row_width: int, device=None):
+    """A flat list of independent frame pairs -- the (candidate, current) pairs of loop-closure validation,
+    PoseGraph.py:463-472 -> :386-410 -> utils/utills.py:1118-1146 -- block-partitioned over the ranks (`shard_list`).
+
+    Rank r tracks only its block and the frames it touches:
+    `run_block(used_frames, f0_local, f1_local, seeds_block) -> (pose[p,3,4], stats[p,8], rows int32[m,row_width],
+    rows_per_pair int[p])`, with pair_f0 / pair_f1 the positions in the caller's frame list and `used_frames` the
+    ascending positions the block needs.  `seeds` (one per pair) are rank 0's: every other rank's argument is ignored,
+    so the result is what one process returns for rank 0's random stream.  No data-path collective; afterwards one
+    all-gather of the 128-byte pose + counter rows and one (ragged) of the supporters' rows leave
+    (pose [P,3,4], stats [P,8], rows [M,row_width], row pointer int64[P+1]) on every rank."""
+    pair_f0, pair_f1 = np.asarray(pair_f0, np.int32), np.asarray(pair_f1, np.int32)
+    P = len(pair_f0)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    seeds = broadcast_array(seeds if rank == 0 else None, (P,), np.int64, device=device).astype(np.uint64)
+    a, b = shard_list(P, rank, world)
+    pose_l, stats_l = np.zeros((0, 3, 4)), np.zeros((0, 8), np.int32)
+    rows_l, cnt_l = np.zeros((0, row_width), np.int32), np.zeros(0, np.int64)
+    if b > a:
+        used, l0, l1 = frames_of_block(pair_f0, pair_f1, a, b)
+        pose_l, stats_l, rows_l, cnt_l = run_block(used, l0, l1, seeds[a:b])
+        if len(pose_l) != b - a or len(cnt_l) != b - a or rows_l.shape[1:] != (row_width,):
+            raise ValueError("run_block returned arrays of the wrong shape for its block")
+    pose, stats = gather_shard_results(pose_l, stats_l, P, device=device)
+    rows, ptr = gather_ragged_rows(np.ascontiguousarray(rows_l, dtype=np.int32), np.asarray(cnt_l, np.int64), P, device=device)
+    return pose, stats, rows, ptr
+
+
 def max_over_ranks(value: int, device=None) -> int:
     if not dist.is_initialized():
         return int(value)

@@ -584,11 +584,6 @@ def _features_of(kp_lr, xy_frame):
     return out
 
 
-def _check_pairs(res):
-    if (res.stats[:, 5] & _lib.SLAM_PAIR_EMPTY).any():
-        raise ValueError("low >= high")          # np.random.randint(0, 0, 4) on an empty tracked set (:502)
-
-
 def find_features_in_consecutive_frames_whole_movie(first_left_ex_cam_mat=M1, movie_len=None, seeds=None):
     """:834-873.  -> (consecutive_frame_features, inliers_percentage, global_trans, relative_trans): the four
     constructor arguments of DataBase (DataBase.py:39).
@@ -778,6 +773,58 @@ def apply_full_consensus_match(first_frame, second_frame):
     return trans, f0, f1, mask, perc
 
 
+def _pair_supporter_rows(frames, pair_f0, pair_f1, seeds):
+    """One device pass over a list of frame pairs, reduced to what loop-closure validation hands on (:1136-1143): per
+    pair the counters, and per supporter ONE 12-word row -- key-point indices (L0, R0, L1, R1) and, as float32 bit
+    patterns, the eight coordinates (xL0, yL0, xR0, yR0, xL1, yL1, xR1, yR1) its two Features are built from.
+    -> (pose float64[P,3,4], stats int32[P,8], rows int32[M,12], rows per pair int64[P])."""
+    pair_f0, pair_f1 = np.asarray(pair_f0, np.int32), np.asarray(pair_f1, np.int32)
+    res, xy, _ = track_pairs_arrays(frames, pair_f0, pair_f1, seeds, host_kp=False)
+    flat, ptr = ops.compact_supporters(res.mask, res.stats[:, 0], res.tracked_kp)
+    cnt = np.diff(ptr)
+    g0, g1 = np.repeat(pair_f0, cnt), np.repeat(pair_f1, cnt)
+    rows = np.empty((len(flat), 12), np.int32)
+    rows[:, :4] = flat
+    coor = rows[:, 4:].view(np.float32)
+    coor[:, 0:2], coor[:, 2:4] = xy[g0, 0, flat[:, 0]], xy[g0, 1, flat[:, 1]]
+    coor[:, 4:6], coor[:, 6:8] = xy[g1, 0, flat[:, 2]], xy[g1, 1, flat[:, 3]]
+    return res.pose, res.stats, rows, cnt
+
+
+def _loop_pair_rows(frames, pair_f0, pair_f1, seeds):
+    """_pair_supporter_rows of the whole pair list: in one process, or -- when the caller has initialised
+    torch.distributed with more than one rank -- block-partitioned over the ranks (slam_amd.dist.track_pairs_sharded:
+    each rank reads, stereo-matches and tracks only the frames its block touches; seeds are rank 0's; the results are
+    all-gathered, so every rank returns the whole list's arrays, equal to the one-process call's).
+    -> (stats int32[P,8], rows int32[M,12], row pointer int64[P+1])."""
+    import torch.distributed as tdist
+    frames = np.asarray(frames)
+    P = len(pair_f0)
+    if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+        from . import dist as sdist
+        if seeds is None and tdist.get_rank() == 0:
+            seeds = np.random.randint(0, 2 ** 32, P, dtype=np.uint64)      # one draw from the global stream per pair
+        _, stats, rows, ptr = sdist.track_pairs_sharded(
+            pair_f0, pair_f1, seeds, lambda used, l0, l1, sd: _pair_supporter_rows(frames[used], l0, l1, sd), 12)
+    else:
+        _, stats, rows, cnt = _pair_supporter_rows(frames, pair_f0, pair_f1, seeds)
+        ptr = np.zeros(P + 1, np.int64)
+        np.cumsum(cnt, out=ptr[1:])
+    if (stats[:, 5] & _lib.SLAM_PAIR_EMPTY).any():
+        raise ValueError("low >= high")          # np.random.randint(0, 0, 4) on an empty tracked set (:502)
+    return stats, rows, ptr
+
+
+def _little_tracks_of_rows(rows, first_frame_id, second_frame_id):
+    """create_little_tracks (:1149-1167) of the supporters' rows of one pair (see _pair_supporter_rows)."""
+    kp, c = rows[:, :4].tolist(), rows[:, 4:].view(np.float32).tolist()
+    f0, f1 = np.empty(len(kp), dtype=object), np.empty(len(kp), dtype=object)
+    for i, (k, x) in enumerate(zip(kp, c)):
+        f0[i] = Feature(k[0], k[1], x[0], x[2], x[1], x[3])
+        f1[i] = Feature(k[2], k[3], x[4], x[6], x[5], x[7])
+    return create_little_tracks(f0, f1, first_frame_id, second_frame_id)
+
+
 def find_loop_cand_by_consensus(mahalanobis_dist_cand_movie_ind, mahalanobis_dist_cand_pg_ind, cur_frame_movie_ind,
                                 threshold, seeds=None):
     """:1118-1146.  All candidates of the current frame go through the device in one pass (each frame's detections
@@ -788,16 +835,12 @@ def find_loop_cand_by_consensus(mahalanobis_dist_cand_movie_ind, mahalanobis_dis
     frames = np.array([int(cur_frame_movie_ind)] + cands)
     pair_f0 = np.arange(1, len(frames), dtype=np.int32)            # candidate = "frame 0" of the pair (:1128-1134)
     pair_f1 = np.zeros(len(cands), np.int32)                       # current frame = "frame 1"
-    res, xy, kp = track_pairs_arrays(frames, pair_f0, pair_f1, seeds)
-    _check_pairs(res)
+    stats, rows, ptr = _loop_pair_rows(frames, pair_f0, pair_f1, seeds)
     passed = []
     for c in range(len(cands)):
-        T = int(res.stats[c, 0])
-        perc = 100 * int(res.stats[c, 1]) / T
-        if perc > threshold:                                       # strict (:1141)
-            sup = kp[c, :T][res.mask[c, :T]]
-            f0, f1 = _features_of(sup[:, :2], xy[1 + c]), _features_of(sup[:, 2:], xy[0])
-            passed.append([mahalanobis_dist_cand_pg_ind[c], create_little_tracks(f0, f1, cands[c], cur_frame_movie_ind)])
+        if 100 * int(stats[c, 1]) / int(stats[c, 0]) > threshold:  # strict (:1141)
+            passed.append([mahalanobis_dist_cand_pg_ind[c],
+                           _little_tracks_of_rows(rows[ptr[c]:ptr[c + 1]], cands[c], cur_frame_movie_ind)])
     return passed
 
 
@@ -807,7 +850,11 @@ def find_loop_cands_by_consensus_batch(cand_movie_ind_lists, cand_pg_ind_lists, 
     as current frame or as candidate, is detected and stereo-matched once; all (candidate, current) pairs go through
     one slam_track_pairs call.  Returns one `[[pg_index, tracks], ...]` list per current frame, each equal to what
     find_loop_cand_by_consensus returns for that frame with the same per-pair seeds (`seeds`: one per pair, in the
-    order current frame by current frame, candidate by candidate)."""
+    order current frame by current frame, candidate by candidate).
+
+    Under torch.distributed with more than one rank (one process per GPU, initialised by the caller) the flat pair list
+    is block-partitioned over the ranks (_loop_pair_rows): the candidates of the key-frame loop are validated on all
+    GPUs of the node, and every rank returns the whole result."""
     curs = [int(c) for c in cur_frame_movie_inds]
     lists = [[int(c) for c in cl] for cl in cand_movie_ind_lists]
     if len(lists) != len(curs) or len(cand_pg_ind_lists) != len(curs):
@@ -819,15 +866,11 @@ def find_loop_cands_by_consensus_batch(cand_movie_ind_lists, cand_pg_ind_lists, 
     out = [[] for _ in curs]
     if len(pair_f0) == 0:
         return out
-    res, xy, kp = track_pairs_arrays(np.array(frames), pair_f0, pair_f1, seeds)
-    _check_pairs(res)
+    stats, rows, ptr = _loop_pair_rows(np.array(frames), pair_f0, pair_f1, seeds)
     p = 0
     for k, (cur, cl) in enumerate(zip(curs, lists)):
         for c, cand in enumerate(cl):
-            T = int(res.stats[p, 0])
-            if 100 * int(res.stats[p, 1]) / T > threshold:                               # strict (:1141)
-                sup = kp[p, :T][res.mask[p, :T]]
-                f0, f1 = _features_of(sup[:, :2], xy[pos[cand]]), _features_of(sup[:, 2:], xy[pos[cur]])
-                out[k].append([cand_pg_ind_lists[k][c], create_little_tracks(f0, f1, cand, cur)])
+            if 100 * int(stats[p, 1]) / int(stats[p, 0]) > threshold:                    # strict (:1141)
+                out[k].append([cand_pg_ind_lists[k][c], _little_tracks_of_rows(rows[ptr[p]:ptr[p + 1]], cand, cur)])
             p += 1
     return out

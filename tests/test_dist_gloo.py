@@ -123,3 +123,69 @@ def test_ragged_rows_and_frames_gather_over_ranks():
             assert np.array_equal(g_ptr, np.concatenate([[0], np.cumsum(counts)]))
             assert g_frames.dtype == np.float32 and np.array_equal(g_frames, frames)
             assert list(seeds) == [7, 8, 9, 10, 11] and widest == 64 * world
+
+
+# ---- loop-closure candidate validation: the flat (candidate, current) pair list split over the ranks ----
+def _loop_case(n_pairs, n_frames=40):
+    rng = np.random.default_rng(9)
+    f1 = np.sort(rng.integers(1, n_frames, n_pairs)).astype(np.int32)                  # current frames, frame by frame
+    f0 = np.array([rng.integers(0, f) for f in f1], np.int32)                          # an earlier candidate each
+    seeds = rng.integers(0, 2 ** 32, n_pairs, dtype=np.uint64)
+    return f0, f1, seeds
+
+
+def _fake_block(frames):
+    """Stand-in for the device pass: a pair's results are a function of its two MOVIE frames and its seed only, so a
+    block that mis-translates frame positions or seeds shows up in the gathered arrays."""
+    def run(used, l0, l1, seeds):
+        g0, g1 = frames[used][l0], frames[used][l1]
+        p = len(l0)
+        pose = np.array([_fake_pose(int(a) * 1000 + int(b)) for a, b in zip(g0, g1)]).reshape(p, 3, 4)
+        stats = np.zeros((p, 8), np.int32)
+        stats[:, 0], stats[:, 1], stats[:, 2], stats[:, 3] = g0, g1, (seeds & 0x7FFFFFFF).astype(np.int32), len(used)
+        cnt = ((g0 + 2 * g1) % 4).astype(np.int64)                                     # some pairs without a row
+        rows = np.array([[a, b, k] + [int(s) & 0xFFFF] * 9 for a, b, s, c in zip(g0, g1, seeds, cnt) for k in range(c)],
+                        np.int32).reshape(-1, 12)
+        return pose, stats, rows, cnt
+    return run
+
+
+def _loop_worker(rank, world, port, n_pairs, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    f0, f1, seeds = _loop_case(n_pairs)
+    frames = np.arange(100, 140)                                                        # movie indices behind the positions
+    mine = seeds if rank == 0 else np.zeros_like(seeds)                                 # only rank 0's seeds may matter
+    q.put((rank,) + sdist.track_pairs_sharded(f0, f1, mine, _fake_block(frames), 12))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pair_list_shards_gather_to_the_single_process_result():
+    """SURVEY 8(e) 'Partitioning', second half: loop-closure validation block-partitions the flat pair list; each rank
+    sees only the frames its block touches.  Worlds 2 and 3, a ragged last block, and a world with more ranks than
+    pairs (a rank with nothing to do)."""
+    frames = np.arange(100, 140)
+    for world, n_pairs in ((2, 11), (3, 10), (3, 2)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_loop_worker, args=(r, world, port, n_pairs, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        f0, f1, seeds = _loop_case(n_pairs)
+        w_pose, w_stats, w_rows, w_cnt = _fake_block(frames)(np.arange(40), f0, f1, seeds)
+        for rank, pose, stats, rows, ptr in got:
+            assert np.array_equal(pose, w_pose) and np.array_equal(stats[:, :3], w_stats[:, :3])
+            assert np.array_equal(rows, w_rows) and np.array_equal(ptr, np.concatenate([[0], np.cumsum(w_cnt)]))
+            # each rank handed its block only the frames that block touches
+            for r in range(world):
+                a, b = sdist.shard_list(n_pairs, r, world)
+                if b > a:
+                    assert (stats[a:b, 3] == len(np.unique(np.concatenate([f0[a:b], f1[a:b]])))).all()
+    used, l0, l1 = sdist.frames_of_block(np.array([5, 9, 5]), np.array([7, 5, 30]), 0, 3)
+    assert used.tolist() == [5, 7, 9, 30] and l0.tolist() == [0, 2, 0] and l1.tolist() == [1, 0, 3]

@@ -279,6 +279,33 @@ def test_results_do_not_depend_on_chunk_plan():
         assert np.array_equal(res.tracked_kp.cpu().numpy(), base.tracked_kp.cpu().numpy()), (chunks, taper)
 
 
+def test_a_pairs_pose_does_not_depend_on_the_size_of_its_launch():
+    """The refit's summation order (wavefronts per pair, LDS or global walk) is a function of the pair's own layout,
+    never of how many pairs share the launch: round 2 switched both on the launch size (768 / 256 pairs), so a pair's pose
+    bits differed between the one-GPU run and an 8-rank or >= 5-chunk run of the same movie.  1100 pairs with ~250
+    supporters each: one call, 2 chunks of 550, 5 chunks of 220, and some pairs in launches of their own."""
+    F = 40
+    cfg = SynthConfig(n_frames=F, n_features=500, seed=33, ragged=True)
+    desc, xy, count = SynthSequence(cfg).frames(0, F)
+    n_max = cfg.n_max
+    args = (dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)))
+    P = 1100
+    f0 = (np.arange(P) % (F - 1)).astype(np.int32)
+    f1 = f0 + 1
+    seeds = 4000 + np.arange(P)
+    base = ShardTracker(F, P, n_max).run(*args, f0, f1, seeds)
+    assert base.ok.all() and np.median(base.supporters) > 64
+    for chunks in (2, 5):
+        res = ShardTracker(F, P, n_max, n_chunks=chunks).run(*args, f0, f1, seeds)
+        assert res.timing_ms[7] == chunks
+        assert np.array_equal(res.pose, base.pose) and np.array_equal(res.mask, base.mask), chunks
+        assert np.array_equal(res.stats[:, :6], base.stats[:, :6]), chunks
+    one = ShardTracker(F, 1, n_max)
+    for p in (0, 500, 1099):
+        res = one.run(*args, f0[p:p + 1], f1[p:p + 1], seeds[p:p + 1])
+        assert np.array_equal(res.pose[0], base.pose[p]) and np.array_equal(res.mask[0], base.mask[p]), p
+
+
 def test_pair_lists_beyond_one_call_are_run_in_blocks(monkeypatch):
     """slam_track_pairs takes at most 65 535 pairs; ShardTracker.run hands a longer list over block by block, each with
     the frame range its pairs touch.  With the block size turned down to 7 the result equals the one-call result, for

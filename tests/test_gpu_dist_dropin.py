@@ -47,3 +47,43 @@ def test_sharded_whole_movie_equals_the_single_process_call(golden, tmp_path, wo
         assert np.array_equal(z["track_ptr"], t.track_ptr) and np.array_equal(z["obs_xy"], t.obs_xy)
         if rank == 0:
             assert int(z["stream_after"]) == after            # rank 0's global stream advanced exactly as one process's does
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_loop_closure_validation_equals_the_single_process_call(golden, tmp_path, world):
+    """SURVEY 8(e), the second split north_star names: the flat (candidate, current) pair list of loop-closure
+    validation (PoseGraph.py:463-472 -> utils/utills.py:1118-1146) block-partitioned over the ranks.  Every rank must
+    return what one process returns for rank 0's random stream: which candidates pass, and every little track (ids,
+    frame ids, key-point indices, coordinates); rank 0's global stream must advance as one process's does.  Six pairs
+    over 2 and 3 ranks (blocks of 3 and of 2); a current frame without candidates; one frame's candidates alone."""
+    import json
+    sys.path.insert(0, HERE)
+    import _dist_dropin_worker as W
+    U.set_detection_source(U.ArrayDetections(golden["movie_desc"], golden["movie_xy"], golden["movie_count"]))
+    want = {}
+    try:
+        for thr in W.LOOP_CASE["thresholds"]:
+            np.random.seed(11)
+            out = U.find_loop_cands_by_consensus_batch(W.LOOP_CASE["cands"], W.LOOP_CASE["pgs"], W.LOOP_CASE["curs"], thr)
+            want[str(thr)] = dict(summary=W.loop_summary(out), stream_after=int(np.random.randint(0, 2 ** 31)))
+        want["one_frame"] = W.loop_summary([U.find_loop_cand_by_consensus([2, 5, 0], [20, 50, 0], 6, 50.0, seeds=np.arange(3) + 5)])
+    finally:
+        U.set_detection_source(None)
+    assert sum(len(c) for c in want["50.0"]["summary"]) == 6 and sum(len(c) for c in want["100.0"]["summary"]) == 0
+    assert 0 < sum(len(c) for c in want["96.5"]["summary"]) < 6
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SLAM_TEST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(HERE, "_dist_dropin_worker.py"), str(tmp_path), "loops"]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-3000:]
+    for rank in range(world):
+        with open(tmp_path / f"loops_rank{rank}.json") as fh:
+            got = json.load(fh)
+        for thr in W.LOOP_CASE["thresholds"]:
+            assert got[str(thr)]["summary"] == want[str(thr)]["summary"]
+            if rank == 0:
+                assert got[str(thr)]["stream_after"] == want[str(thr)]["stream_after"]
+        assert got["one_frame"] == want["one_frame"]

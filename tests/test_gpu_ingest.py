@@ -104,14 +104,19 @@ def test_unpack_treats_an_image_outside_the_dense_arrays_as_empty():
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     dense = dev(np.full((rows, width), 7, np.uint8))
     xy = dev(np.ones((rows, 2), np.float32))
-    row_ptr = dev(np.array([0, 90, -5, 60], np.int64))
-    count = dev(np.array([10, 20, 3, 999], np.int32))          # 90 + 20 > 100; negative start; 999 clamps to 64, 60 + 64 > 100
-    out_d = torch.full((4, n_max, 64), 255, dtype=torch.uint8, device="cuda")
-    out_x = torch.full((4, n_max, 2), -1.0, dtype=torch.float32, device="cuda")
-    out_c = torch.full((4,), -1, dtype=torch.int32, device="cuda")
-    _lib.check(_lib.lib().slam_unpack_detections(dense.data_ptr(), xy.data_ptr(), row_ptr.data_ptr(), count.data_ptr(), 4, n_max, width,
+    big = np.iinfo(np.int64).max
+    # 90 + 20 > 100; negative start; 999 clamps to 64, 60 + 64 > 100; a pointer whose `start + rows` wraps around int64
+    # (must not pass the range test); the same one short of wrapping; one row past the last admissible start
+    row_ptr = dev(np.array([0, 90, -5, 60, big, big - 70, rows - 5 + 1], np.int64))
+    count = dev(np.array([10, 20, 3, 999, 64, 64, 5], np.int32))
+    n_img = 7
+    out_d = torch.full((n_img, n_max, 64), 255, dtype=torch.uint8, device="cuda")
+    out_x = torch.full((n_img, n_max, 2), -1.0, dtype=torch.float32, device="cuda")
+    out_c = torch.full((n_img,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().slam_unpack_detections(dense.data_ptr(), xy.data_ptr(), row_ptr.data_ptr(), count.data_ptr(), n_img, n_max, width,
                                                  rows, out_d.data_ptr(), out_x.data_ptr(), out_c.data_ptr(), ops._stream()))
-    assert out_c.cpu().tolist() == [10, 0, 0, 0]
+    torch.cuda.synchronize()
+    assert out_c.cpu().tolist() == [10, 0, 0, 0, 0, 0, 0]
     d = out_d.cpu().numpy()
     assert (d[0, :10, :61] == 7).all() and not d[0, :10, 61:].any() and not d[0, 10:].any() and not d[1:].any()
     assert float(out_x[0, :10].min()) == 1.0 and not out_x[0, 10:].any() and not out_x[1:].any()

@@ -27,9 +27,14 @@ def _descs(rng, n, values):
     return torch.from_numpy(ops.pad_descriptors(rng.integers(0, values, (n, 61), dtype=np.uint8))).cuda()
 
 
-@pytest.mark.parametrize("mode", [_lib.SLAM_MATCH_CROSSCHECK, _lib.SLAM_MATCH_KNN2])
+MODES = [_lib.SLAM_MATCH_CROSSCHECK, _lib.SLAM_MATCH_KNN2, _lib.SLAM_MATCH_CROSSCHECK_MUTUAL]
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("norm", [_lib.SLAM_NORM_HAMMING2, _lib.SLAM_NORM_HAMMING])
 def test_noalloc_equals_existing_entry_point_on_two_calls_second_smaller(norm, mode):
+    """All three rules; the mutual one is the only user of the column-minima region of the static array, where tiles
+    without rows are never rewritten, so the first call's contents stay behind the second, smaller call."""
     L = _lib.lib()
     rng = np.random.default_rng(77 + norm + 10 * mode)
     # few distinct byte values -> many equal distances -> tie-breaks matter; first call large (many B splits), second small
@@ -40,11 +45,13 @@ def test_noalloc_equals_existing_entry_point_on_two_calls_second_smaller(norm, m
             for nq, _ in shapes]
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]                       # hipMemGetInfo: the device's free memory
     for (q, t), (k1, k2) in zip(inputs, outs):                       # back to back on one stream, nothing in between
         rc = L.slam_match_hamming_noalloc(_ptr(q), q.shape[0], _ptr(t), t.shape[0], norm, mode, _ptr(k1),
                                           _ptr(k2) if mode == _lib.SLAM_MATCH_KNN2 else None, stream)
         assert rc == _lib.SLAM_OK, L.slam_last_error_string()
     torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before               # the calls took no device memory
     for (k1, k2), (w1, w2) in zip(outs, want):
         assert np.array_equal(k1.cpu().numpy(), w1)
         if mode == _lib.SLAM_MATCH_KNN2:
@@ -87,3 +94,41 @@ def test_noalloc_empty_inputs():
     assert L.slam_match_hamming_noalloc(_ptr(t), 10, None, 0, 7, 0, _ptr(k1), None, stream) == _lib.SLAM_OK
     torch.cuda.synchronize()
     assert bool((k1 == -1).all())                                     # no train rows: every query unmatched
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_noalloc_calls_can_be_captured_in_a_hip_graph_and_replayed(mode):
+    """What the entry point exists for: a caller under HIP graph capture, where hipMalloc / hipFree (and anything else
+    that synchronises the device) is an error.  After one warm-up call (which looks the static array's address up), two
+    calls are captured into a graph -- capture fails if either allocates -- the outputs are cleared, the graph is
+    replayed, and the replayed results must equal slam_match_hamming's."""
+    L = _lib.lib()
+    norm = _lib.SLAM_NORM_HAMMING2
+    rng = np.random.default_rng(300 + mode)
+    shapes = [(2500, 4100), (600, 290)]
+    inputs = [(_descs(rng, nq, 4), _descs(rng, nt, 4)) for nq, nt in shapes]
+    want = [_existing(q, t, norm, mode) for q, t in inputs]
+    outs = [(torch.zeros(nq, dtype=torch.int32, device="cuda"), torch.zeros(nq, dtype=torch.int32, device="cuda"))
+            for nq, _ in shapes]
+
+    def calls():
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for (q, t), (k1, k2) in zip(inputs, outs):
+            rc = L.slam_match_hamming_noalloc(_ptr(q), q.shape[0], _ptr(t), t.shape[0], norm, mode, _ptr(k1),
+                                              _ptr(k2) if mode == _lib.SLAM_MATCH_KNN2 else None, stream)
+            assert rc == _lib.SLAM_OK, L.slam_last_error_string()
+
+    calls()                                                           # warm-up: hipGetSymbolAddress happens here
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):                                     # capture_error_mode "global": an allocation anywhere fails it
+        calls()
+    for k1, k2 in outs:
+        k1.fill_(-7)
+        k2.fill_(-7)
+    graph.replay()
+    torch.cuda.synchronize()
+    for (k1, k2), (w1, w2) in zip(outs, want):
+        assert np.array_equal(k1.cpu().numpy(), w1)
+        if mode == _lib.SLAM_MATCH_KNN2:
+            assert np.array_equal(k2.cpu().numpy(), w2)
