@@ -68,12 +68,16 @@ def parse(argv=None):
     ap.add_argument("--cpu-pairs-all-cores", type=int, default=1920, help="frame pairs timed through the oracle on all host cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--chunks", type=int, default=2, help="frame-range chunks pipelined over two HIP streams per GPU")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="frame-range chunks pipelined over two HIP streams per GPU (0 = the library's plan: 2 for a large shard, 1 for a small one)")
     ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto",
                     help="auto (default): N > 1 times the strong leg (value) and the weak leg (reported beside it); "
                          "weak / strong: only that leg")
     ap.add_argument("--first-chunk", type=int, default=0, help="hypotheses evaluated speculatively per pair in RANSAC round 0 (0 = library default)")
     ap.add_argument("--taper", type=float, default=1.0, help="each chunk's size relative to the previous one (1 = equal)")
+    ap.add_argument("--serial-match", type=int, default=-1, choices=(-1, 0, 1),
+                    help="1: the chunks' matchers run back to back, each chunk's tail beside the next matcher; 0: chunks on "
+                         "different streams start together; -1 (default): the tracker's own choice for the shard size")
     ap.add_argument("--no-ingest", action="store_true", help="skip the PCIe-inclusive leg (reported beside, never as, value)")
     ap.add_argument("--no-dropin", action="store_true", help="skip timing the reference-shaped whole-movie call")
     ap.add_argument("--match-rule", choices=("ocv_legacy", "mutual", "knn"), default="ocv_legacy",
@@ -215,7 +219,8 @@ def trajectory_leg(args, rk: Rank, scaling: str):
     f0, f1 = pipeline.consecutive_pairs(F)
     P = len(f0)
     seeds = 1000 + first_pair + np.arange(P)                  # np.random.seed(1000 + pair index)
-    trk = pipeline.ShardTracker(max(F, 1), max(P, 1), n_max, hot_path_config(args), n_chunks=args.chunks, taper=args.taper)
+    trk = pipeline.ShardTracker(max(F, 1), max(P, 1), n_max, hot_path_config(args), n_chunks=args.chunks, taper=args.taper,
+                                serial_match=None if args.serial_match < 0 else bool(args.serial_match))
 
     n_compose = F_total - 1                                   # rank 0 composes the first movie's trajectory
     rel_buf = np.empty((n_compose + 1, 3, 4))

@@ -269,7 +269,8 @@ typedef struct SlamTrackConfig {
     int32_t max_draws;       /* bound on draws incl. failed ones (the reference is unbounded); 0 = 64 * max_iterations */
     int32_t norm;            /* SLAM_NORM_HAMMING2 */
     int32_t first_chunk;     /* hypotheses evaluated speculatively in round 1 (0 = 64) */
-    int32_t pipeline_chunks; /* > 1: split the pair list into this many contiguous blocks and pipeline them over two
+    int32_t pipeline_chunks; /* 0: the library chooses (two blocks for a large shard, one for a small one);
+                                > 1: split the pair list into this many contiguous blocks and pipeline them over two
                                 internal streams (RANSAC rounds of one block overlap the matching of the next);
                                 needs pairs that are local in time, otherwise the call falls back to one block */
     int32_t pipeline_taper_permille; /* size of each block relative to the previous one, in 1/1000: 0 or 1000 = equal
@@ -278,7 +279,10 @@ typedef struct SlamTrackConfig {
     int32_t match_mode;      /* how match() pairs descriptors (utils/utills.py:105-119): SLAM_MATCH_CROSSCHECK (default,
                                 MATCH_METHOD = BRUTE_FORCE), SLAM_MATCH_CROSSCHECK_MUTUAL, or SLAM_MATCH_KNN2
                                 (REGULAR_KNN: two nearest + the ratio test below) */
-    int32_t reserved_;
+    int32_t pipeline_serial_match; /* with pipeline_chunks > 1: nonzero = a block's matcher starts only when the previous
+                                block's matcher has finished (the blocks' matchers run back to back, each block's
+                                RANSAC / refit beside the NEXT block's matcher); 0 = blocks on different streams start
+                                together.  Scheduling only: results do not depend on it. */
     double ratio;            /* RATIO = 0.6 (utils/utills.py:23); used by SLAM_MATCH_KNN2 only; 0 = 0.6 */
 } SlamTrackConfig;
 
@@ -295,6 +299,8 @@ typedef struct SlamTrackIO {
     /* device outputs (caller-allocated) */
     int32_t *d_tracked_kp;   /* [n_pairs][n_max][4] */
     /* host outputs (caller-allocated) */
+    /* h_pose and h_mask should be page-locked (hipHostMalloc / hipHostRegister, torch pin_memory): the library then
+       queues the result copies ahead of time; with pageable memory it still works, one host round trip slower per block */
     double *h_pose;          /* [n_pairs][12]; NaN where the reference returns None */
     int32_t *h_stats;        /* [n_pairs][8]: tracked T, supporters, iterations, draws, best draw, status, stereo0 matches, temporal matches */
     uint64_t *h_mask;        /* [n_pairs][n_max/64] supporter bit masks (pre-refit, as the reference returns) */

@@ -33,7 +33,7 @@ class SlamTrackConfig(ctypes.Structure):
                 ("acc", c_double), ("prob", c_double), ("max_iterations", c_double),
                 ("fixed_iterations", ctypes.c_int32), ("max_draws", ctypes.c_int32), ("norm", ctypes.c_int32),
                 ("first_chunk", ctypes.c_int32), ("pipeline_chunks", ctypes.c_int32), ("pipeline_taper_permille", ctypes.c_int32),
-                ("match_mode", ctypes.c_int32), ("reserved_", ctypes.c_int32), ("ratio", c_double)]
+                ("match_mode", ctypes.c_int32), ("pipeline_serial_match", ctypes.c_int32), ("ratio", c_double)]
 
 
 class SlamTrackIO(ctypes.Structure):

@@ -28,9 +28,11 @@ int slam_launch_p3p(const Mat33 &K, const double *d_X, const void *d_xy1, int xy
 int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count,
                       const int32_t *d_seg_of, int n_rows, int seg_stride, const double *d_pose,
                       const uint8_t *d_status, int n_hyp, double thr, int32_t *d_inlier_count, uint64_t *d_mask,
-                      hipStream_t st);
+                      hipStream_t st, const int32_t *d_gate = nullptr);
 int slam_launch_refit(const Mat33 &K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count, int n_seg,
                       int seg_stride, const uint64_t *d_mask_words, const double *d_pose0, double *d_pose,
-                      uint8_t *d_status, hipStream_t st);
+                      uint8_t *d_status, hipStream_t st, const int32_t *d_gate = nullptr);
+// d_gate (both launchers above; optional): device word read when the kernel starts -- unless it is zero the kernel
+// returns without touching its outputs (work queued speculatively behind a device-side decision, pipeline.hip).
 int slam_launch_triangulate(const Mat34 &P, const Mat34 &Q, const float *d_xy, const int32_t *d_count, int n_seg,
                             int seg_stride, double *d_X, hipStream_t st);

@@ -55,6 +55,12 @@ struct Buffers {
     double *pose0, *best_pose, *refit_pose;
     uint8_t *status0, *best_status, *refit_status;
     uint64_t *mask;
+    // Everything the host reads after round 0 sits in ONE device block (r0: tcount | aux | produced0 | dev_best | gate |
+    // cnt0 | status0) with a pinned mirror, and the per-pair results that do not go straight into the caller's arrays
+    // in another (tail: best_cnt | refit_status): one copy each instead of five and two.  The sub-arrays are placed for
+    // the chunk's own pair count (bind_blocks), so a copy moves exactly the chunk's bytes.
+    int32_t *r0, *tail, *h_r0, *h_tail;
+    int32_t *dev_best, *gate, *h_dev_best, *h_gate;
     // later-round sub-batches alternate between two slots, so that the host prepares / replays one while the GPU
     // evaluates the other
     int32_t *seg_of[2], *beginR[2], *sampleR[2], *cntR[2], *best_idxR[2];
@@ -72,6 +78,36 @@ struct Buffers {
 };
 
 int first_chunk(const SlamTrackConfig *cfg) { return cfg && cfg->first_chunk > 0 ? cfg->first_chunk : 64; }
+
+size_t r0_words(size_t P, int D0) { return P * (size_t)(5 + D0) + 4 + (P * (size_t)D0 + 3) / 4; }
+size_t tail_words(size_t P) { return P + (P + 3) / 4; }
+
+struct R0View { int32_t *tcount, *aux, *produced0, *dev_best, *gate, *cnt0; uint8_t *status0; };
+R0View r0_view(int32_t *base, size_t P, int D0) {
+    R0View v{};
+    if (!base) return v;
+    v.tcount = base;
+    v.aux = base + P;
+    v.produced0 = base + 3 * P;
+    v.dev_best = base + 4 * P;
+    v.gate = base + 5 * P;                    // 4 words, the first is the gate
+    v.cnt0 = base + 5 * P + 4;
+    v.status0 = (uint8_t *)(v.cnt0 + P * (size_t)D0);
+    return v;
+}
+
+// places the packed blocks' sub-arrays for a chunk of P pairs (P <= the capacity the blocks were carved for)
+void bind_blocks(Buffers &b, size_t P) {
+    const R0View d = r0_view(b.r0, P, b.D0), h = r0_view(b.h_r0, P, b.D0);
+    b.tcount = d.tcount, b.aux = d.aux, b.produced0 = d.produced0, b.dev_best = d.dev_best, b.gate = d.gate;
+    b.cnt0 = d.cnt0, b.status0 = d.status0;
+    b.h_tcount = h.tcount, b.h_aux = h.aux, b.h_produced0 = h.produced0, b.h_dev_best = h.dev_best, b.h_gate = h.gate;
+    b.h_cnt0 = h.cnt0, b.h_status0 = h.status0;
+    b.best_cnt = b.tail;
+    b.refit_status = b.tail ? (uint8_t *)(b.tail + P) : nullptr;
+    b.h_best_cnt = b.h_tail;
+    b.h_refit_status = b.h_tail ? (uint8_t *)(b.h_tail + P) : nullptr;
+}
 
 void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carver &h, Buffers &b) {
     const size_t Fs = F, Ps = P, N = n_max;
@@ -92,23 +128,18 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     b.pair_f1 = b.setup ? b.pair_f0 + Ps : nullptr;
     b.seed = b.setup ? (uint32_t *)(b.pair_f1 + Ps) : nullptr;
     b.order = b.setup ? b.pair_f1 + 2 * Ps : nullptr;
-    b.tcount = d.take<int32_t>(Ps);
-    b.aux = d.take<int32_t>(2 * Ps);
+    b.r0 = d.take<int32_t>(r0_words(Ps, b.D0));
+    b.tail = d.take<int32_t>(tail_words(Ps));
     b.xy0 = d.take<float>(Ps * N * 4);
     b.xy1 = d.take<float>(Ps * N * 4);
     b.X = d.take<double>(Ps * N * 3);
     b.sample0 = d.take<int32_t>(Ps * b.D0 * 4);
-    b.produced0 = d.take<int32_t>(Ps);
     b.pose0 = d.take<double>(Ps * b.D0 * 12);
-    b.status0 = d.take<uint8_t>(Ps * b.D0);
-    b.cnt0 = d.take<int32_t>(Ps * b.D0);
     b.best_idx = d.take<int32_t>(Ps);
     b.best_pose = d.take<double>(Ps * 12);
     b.best_status = d.take<uint8_t>(Ps);
-    b.best_cnt = d.take<int32_t>(Ps);
     b.mask = d.take<uint64_t>(Ps * (N / 64));
     b.refit_pose = d.take<double>(Ps * 12);
-    b.refit_status = d.take<uint8_t>(Ps);
     for (int k = 0; k < 2; ++k) {
         b.seg_of[k] = d.take<int32_t>(b.RB);
         b.beginR[k] = d.take<int32_t>(b.RB);
@@ -120,14 +151,9 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     }
 
     b.h_prob = h.take<int32_t>(3 * (Fs + Ps) + 3 * Ps);   // mirrors `setup`
-    b.h_tcount = h.take<int32_t>(Ps);
-    b.h_aux = h.take<int32_t>(2 * Ps);
-    b.h_produced0 = h.take<int32_t>(Ps);
-    b.h_status0 = h.take<uint8_t>(Ps * b.D0);
-    b.h_cnt0 = h.take<int32_t>(Ps * b.D0);
+    b.h_r0 = h.take<int32_t>(r0_words(Ps, b.D0));
+    b.h_tail = h.take<int32_t>(tail_words(Ps));
     b.h_best_idx = h.take<int32_t>(Ps);
-    b.h_best_cnt = h.take<int32_t>(Ps);
-    b.h_refit_status = h.take<uint8_t>(Ps);
     for (int k = 0; k < 2; ++k) {
         b.h_seg_of[k] = h.take<int32_t>(b.RB);
         b.h_beginR[k] = h.take<int32_t>(b.RB);
@@ -135,6 +161,7 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
         b.h_cntR[k] = h.take<int32_t>(HYP_BUDGET);
         b.h_best_idxR[k] = h.take<int32_t>(b.RB);
     }
+    bind_blocks(b, Ps);
 }
 
 // best_idx[row] >= 0: copy pose/status of that hypothesis to the segment's "best" slot
@@ -149,6 +176,87 @@ __global__ void gather_best_kernel(const double *pose, const uint8_t *status, co
     const size_t o = (size_t)row * n_hyp + bi;
     best_pose[(size_t)seg * 12 + k] = pose[o * 12 + k];
     if (k == 0) best_status[seg] = status[o];
+}
+
+// Round 0 of the adaptive loop replayed ON THE DEVICE, one wavefront per pair, so that the winner's mask and the refit
+// can be queued behind it without a host round trip.  It is a PREDICTION: the host replays the same loop from the
+// downloaded (status, count) arrays (RansacReplay, the authority -- its log / pow are libm's, as numpy's) while the
+// speculative kernels run, and accepts their results only if every pair's loop finished inside round 0 with the same
+// winner; otherwise the call falls back to the host-driven path.  `gate` counts the pairs whose loop wants more draws:
+// the speculative mask / refit kernels return at once when it is not zero, so a shard that needs later rounds
+// (loop-closure validation of unrelated frames) pays two empty launches, not a wasted refit.
+//
+// The loop (utils/utills.py:498-523) as prefix sums over a pair's draws d = 0 .. end (lane = draw): counted iterations,
+// cumulative inliers / outliers and hence the outlier ratio BEFORE draw d are exclusive scans; the loop stops at the
+// first d whose "more" test fails (d = end stands for the state after the last evaluated draw); the winner is the
+// first maximum of the counts among the solved draws before the stop.
+__global__ __launch_bounds__(64) void replay0_kernel(const int *tcount, const int *produced, const uint8_t *status, const int *cnt,
+                                                     const double *pose, int D0, double log1mp, double max_it, int fixed_it,
+                                                     int *dev_best, double *best_pose, uint8_t *best_status, int *gate) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int n = tcount[p];
+    const int end = n > 0 ? produced[p] : 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int it = 0;
+    long long inl = 0, outl = 0, best_key = -1;
+    bool finished = n <= 0;
+    for (int base = 0; base <= end && !finished; base += 64) {
+        const int d = base + lane;
+        const bool ok = d < end && status[(size_t)p * D0 + d] != 0;
+        const int c = ok ? cnt[(size_t)p * D0 + d] : 0;
+        const unsigned long long okmask = __ballot(ok);
+        int incl = c;                                   // inclusive scan of the counts over the lanes
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) {
+            const int up = __shfl_up(incl, k);
+            if (lane >= k) incl += up;
+        }
+        const int before = __popcll(okmask & lt);       // counted iterations of this tile before draw d
+        const int it_b = it + before;
+        const long long inl_b = inl + (incl - c), outl_b = outl + (long long)n * before - (incl - c);
+        bool more;
+        if (fixed_it > 0) {
+            more = it_b < fixed_it;
+        } else {
+            double perc = 0.99;
+            if (it_b > 0) {
+                const double q = (double)outl_b / (double)(inl_b + outl_b);
+                perc = q < 0.99 ? q : 0.99;
+            }
+            if (perc == 0.0) {
+                more = false;
+            } else {
+                const double est = log1mp / log(1.0 - pow(1.0 - perc, 4.0));
+                more = (double)it_b < est && (double)it_b < max_it;
+            }
+        }
+        const unsigned long long stopmask = __ballot(d <= end && !more);
+        int stop = base + 64;                           // first draw of the tile the loop does not consume
+        if (stopmask) {
+            stop = base + __ffsll((long long)stopmask) - 1;
+            finished = true;
+        }
+        long long key = ok && d < stop ? ((long long)c << 32) | (long long)(0x7fffffff - d) : -1;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const long long o = __shfl_xor(key, m);
+            key = o > key ? o : key;
+        }
+        if (key > best_key) best_key = key;             // equal counts: the earlier tile's draw stays (strict >, :514)
+        const int total = __shfl(incl, 63), n_ok = __popcll(okmask);
+        it += n_ok;
+        inl += total;
+        outl += (long long)n * n_ok - total;
+    }
+    const int best = best_key >= 0 ? 0x7fffffff - (int)(best_key & 0x7fffffff) : -1;
+    if (lane == 0) {
+        dev_best[p] = best;
+        best_status[p] = best >= 0 ? status[(size_t)p * D0 + best] : 0;
+        if (!finished) atomicAdd(gate, 1);
+    }
+    if (lane < 12)
+        best_pose[(size_t)p * 12 + lane] = best >= 0 ? pose[((size_t)p * D0 + best) * 12 + lane]
+                                                     : __longlong_as_double(-1ll);      // the 0xFF.. NaN pattern of the memset
 }
 
 template <typename F>
@@ -170,7 +278,20 @@ struct Shared {
     RansacParams rp;
     double thr, ratio;
     int norm, N, match_mode;
+    bool outputs_pinned;             // h_pose / h_mask are page-locked: copies into them can be queued without blocking
 };
+
+// page-locked (hipHostMalloc / hipHostRegister) host memory?  A copy into pageable memory blocks the queueing thread
+// until it has been carried out, so work is only queued speculatively ahead of such a copy when this holds.
+bool host_pinned(const void *p) {
+    hipPointerAttribute_t a{};
+    const hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
 
 // One workspace + one stream: a chunk of the shard goes through front() -> mid() -> back().
 struct Lane {
@@ -178,7 +299,11 @@ struct Lane {
     hipStream_t st = nullptr;
     hipEvent_t ev[6];
     hipEvent_t evR[2];                               // results of a later-round sub-batch have arrived (per slot)
+    hipEvent_t evA = nullptr;                        // round 0 has been downloaded
+    hipEvent_t ev_matched = nullptr;                 // the chunk's matcher has finished
+    hipEvent_t match_after = nullptr;                // event the chunk's matcher waits for (serial matchers), or null
     bool ev_ready = false;
+    bool speculative = false;                        // the chunk's mask / refit were queued behind the device-side replay
     // the chunk in flight
     int F = 0, P = 0, pair0 = 0;
     const uint8_t *d_desc = nullptr;
@@ -196,6 +321,8 @@ struct Lane {
         if (!ev_ready) {
             for (auto &e : ev) SLAM_HIP_CHECK(hipEventCreate(&e));
             for (auto &e : evR) SLAM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            SLAM_HIP_CHECK(hipEventCreateWithFlags(&evA, hipEventDisableTiming));
+            SLAM_HIP_CHECK(hipEventCreateWithFlags(&ev_matched, hipEventDisableTiming));
             ev_ready = true;
         }
         return SLAM_OK;
@@ -216,6 +343,7 @@ struct Lane {
             f1[p] = io->h_pair_f1[a + p] - lo;
         }
         seed = io->h_pair_seed + a;
+        bind_blocks(b, (size_t)P);
     }
 
     // everything up to the first host decision, asynchronously: match, join, triangulate, RANSAC round 0, D2H
@@ -255,13 +383,16 @@ struct Lane {
                 h_order[++order_fill[f]] = F + p;
             }
             SLAM_HIP_CHECK(hipMemcpyAsync(b.setup, b.h_prob, sizeof(int32_t) * b.setup_len, hipMemcpyHostToDevice, st));
+            SLAM_HIP_CHECK(hipMemsetAsync(b.gate, 0, 4 * sizeof(int32_t), st));
         }
+        if (match_after) SLAM_HIP_CHECK(hipStreamWaitEvent(st, match_after, 0));    // serial matchers: the previous chunk's has finished
         SLAM_HIP_CHECK(hipEventRecord(ev[0], st));
         // ---- 1. matching: F stereo + P temporal problems, ONE launch over the contiguous key array ----
         rc = slam_launch_match_batched(d_desc, d_count, N, b.prob_q, b.prob_t, b.order, F + P, sh.norm, sh.match_mode,
                                        sh.ratio, b.stereo_key, b.key2, b.match_ws, b.match_ws_bytes, st);
         if (rc) return rc;
         SLAM_HIP_CHECK(hipEventRecord(ev[1], st));
+        SLAM_HIP_CHECK(hipEventRecord(ev_matched, st));
         // ---- 2. join, 3. triangulate ----
         rc = slam_launch_rect_join(d_xy, d_count, N, b.stereo_key, b.temporal_key_at(F, N), b.pair_f0, b.pair_f1, P,
                                    sh.cfg->rec_err, b.tcount, sh.io->d_tracked_kp + (size_t)pair0 * N * 4, b.xy0, b.xy1,
@@ -279,11 +410,40 @@ struct Lane {
         rc = slam_launch_score(sh.K, sh.M2, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.pose0, b.status0, D0, sh.thr, b.cnt0,
                                nullptr, st);
         if (rc) return rc;
-        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_tcount, b.tcount, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
-        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_aux, b.aux, sizeof(int32_t) * 2 * P, hipMemcpyDeviceToHost, st));
-        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_produced0, b.produced0, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
-        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_status0, b.status0, (size_t)P * D0, hipMemcpyDeviceToHost, st));
-        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_cnt0, b.cnt0, sizeof(int32_t) * (size_t)P * D0, hipMemcpyDeviceToHost, st));
+        // device-side replay of round 0 (a prediction the host verifies in mid()), then ONE download of everything the
+        // host replay reads, then -- speculatively, gated on "no pair wants another round" -- the winner's mask, the
+        // refit and the result downloads, so that a chunk whose pairs all finish in round 0 needs no host round trip
+        speculative = sh.rp.max_draws > D0 && sh.outputs_pinned;
+        if (speculative) {
+            hipLaunchKernelGGL(replay0_kernel, dim3(P), dim3(64), 0, st, b.tcount, b.produced0, b.status0, b.cnt0, b.pose0, D0,
+                               std::log(1.0 - sh.rp.prob), sh.rp.max_iterations, sh.rp.fixed_iterations, b.dev_best, b.best_pose,
+                               b.best_status, b.gate);
+            SLAM_HIP_CHECK(hipGetLastError());
+        }
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_r0, b.r0, sizeof(int32_t) * r0_words(P, D0), hipMemcpyDeviceToHost, st));
+        SLAM_HIP_CHECK(hipEventRecord(evA, st));
+        if (speculative) {
+            SLAM_HIP_CHECK(hipEventRecord(ev[4], st));
+            rc = finish_chunk(sh, b.gate);
+            if (rc) return rc;
+        }
+        return SLAM_OK;
+    }
+
+    // the winner's supporter mask (pre-refit, as the reference returns) + the refit + the downloads of the results;
+    // with `gate` the two kernels do nothing unless *gate == 0 (see replay0_kernel)
+    int finish_chunk(const Shared &sh, const int *gate) {
+        const int N = sh.N;
+        int rc = slam_launch_score(sh.K, sh.M2, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.best_pose, b.best_status, 1, sh.thr,
+                                   b.best_cnt, b.mask, st, gate);
+        if (rc) return rc;
+        rc = slam_launch_refit(sh.K, b.X, b.xy1, 0, b.tcount, P, N, b.mask, b.best_pose, b.refit_pose, b.refit_status, st, gate);
+        if (rc) return rc;
+        SLAM_HIP_CHECK(hipEventRecord(ev[5], st));
+        const SlamTrackIO *io = sh.io;
+        SLAM_HIP_CHECK(hipMemcpyAsync(io->h_pose + (size_t)pair0 * 12, b.refit_pose, sizeof(double) * 12 * (size_t)P, hipMemcpyDeviceToHost, st));
+        SLAM_HIP_CHECK(hipMemcpyAsync(io->h_mask + (size_t)pair0 * (N / 64), b.mask, sizeof(uint64_t) * (size_t)P * (N / 64), hipMemcpyDeviceToHost, st));
+        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_tail, b.tail, sizeof(int32_t) * tail_words(P), hipMemcpyDeviceToHost, st));
         return SLAM_OK;
     }
 
@@ -291,7 +451,7 @@ struct Lane {
     int mid(const Shared &sh) {
         const int N = sh.N, D0 = b.D0;
         const RansacParams &rp = sh.rp;
-        SLAM_HIP_CHECK(hipStreamSynchronize(st));
+        SLAM_HIP_CHECK(hipEventSynchronize(evA));           // round 0 has been downloaded (the speculative tail may still run)
         double t_h0 = now_ms();
         rs.assign(P, RansacReplay());
         active.clear();
@@ -306,9 +466,13 @@ struct Lane {
                 b.h_best_idx[p] = r.best_draw;
             }
         });
-        for (int p = 0; p < P; ++p)
+        bool agree = speculative && b.h_gate[0] == 0;
+        for (int p = 0; p < P; ++p) {
             if (!rs[p].finished) active.push_back(p);
+            else if (agree && b.h_dev_best[p] != rs[p].best_draw) agree = false;
+        }
         host_ms += now_ms() - t_h0;
+        if (agree && active.empty()) return SLAM_OK;          // the speculative mask / refit / downloads stand
         SLAM_HIP_CHECK(hipMemsetAsync(b.best_status, 0, P, st));
         SLAM_HIP_CHECK(hipMemsetAsync(b.best_pose, 0xFF, sizeof(double) * 12 * (size_t)P, st));   // NaN pattern
         SLAM_HIP_CHECK(hipMemcpyAsync(b.best_idx, b.h_best_idx, sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
@@ -425,19 +589,8 @@ struct Lane {
             active.swap(still);
         }
         SLAM_HIP_CHECK(hipEventRecord(ev[4], st));
-        // ---- 5. supporter mask of the winner (pre-refit, as the reference returns) + refit ----
-        rc = slam_launch_score(sh.K, sh.M2, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.best_pose, b.best_status, 1, sh.thr,
-                               b.best_cnt, b.mask, st);
-        if (rc) return rc;
-        rc = slam_launch_refit(sh.K, b.X, b.xy1, 0, b.tcount, P, N, b.mask, b.best_pose, b.refit_pose, b.refit_status, st);
-        if (rc) return rc;
-        SLAM_HIP_CHECK(hipEventRecord(ev[5], st));
-        const SlamTrackIO *io = sh.io;
-        SLAM_HIP_CHECK(hipMemcpyAsync(io->h_pose + (size_t)pair0 * 12, b.refit_pose, sizeof(double) * 12 * (size_t)P, hipMemcpyDeviceToHost, st));
-        SLAM_HIP_CHECK(hipMemcpyAsync(io->h_mask + (size_t)pair0 * (N / 64), b.mask, sizeof(uint64_t) * (size_t)P * (N / 64), hipMemcpyDeviceToHost, st));
-        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_best_cnt, b.best_cnt, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
-        SLAM_HIP_CHECK(hipMemcpyAsync(b.h_refit_status, b.refit_status, P, hipMemcpyDeviceToHost, st));
-        return SLAM_OK;
+        // ---- 5. supporter mask of the winner + refit, on the host replay's winners ----
+        return finish_chunk(sh, nullptr);
     }
 
     // wait for the chunk's results and write its per-pair counters
@@ -513,6 +666,8 @@ struct ThreadState {
             if (ln.ev_ready) {
                 for (auto &e : ln.ev) (void)hipEventDestroy(e);
                 for (auto &e : ln.evR) (void)hipEventDestroy(e);
+                (void)hipEventDestroy(ln.evA);
+                (void)hipEventDestroy(ln.ev_matched);
                 ln.ev_ready = false;
             }
         if (fork) {
@@ -586,9 +741,18 @@ std::vector<int> chunk_sizes(int P, int n_chunks, int taper) {
     return out;
 }
 
+// pipeline_chunks <= 0: the library's own plan.  Two lanes pay when each half still fills the chip for long enough
+// that one lane's latency-bound steps (small kernels, copies, the host replay) hide behind the other's matcher: from
+// about a third of a 3450-frame x 2048-row shard; below that the halves' small kernels only wait for each other
+// (433 frames: 2.36 ms in one lane, 2.60 in two; 3450 frames: 15.8 against 15.4).
+int planned_chunks(int n_pairs, int n_max, const SlamTrackConfig *cfg) {
+    if (cfg->pipeline_chunks > 0) return cfg->pipeline_chunks;
+    return (double)n_pairs * n_max * n_max >= 1200.0 * 2048.0 * 2048.0 ? 2 : 1;
+}
+
 std::vector<Chunk> plan_chunks(const SlamTrackIO *io, const SlamTrackConfig *cfg) {
     std::vector<Chunk> out;
-    const std::vector<int> sizes = chunk_sizes(io->n_pairs, cfg->pipeline_chunks, cfg->pipeline_taper_permille);
+    const std::vector<int> sizes = chunk_sizes(io->n_pairs, planned_chunks(io->n_pairs, io->n_max, cfg), cfg->pipeline_taper_permille);
     int a = 0;
     for (int n : sizes) {
         const int e = a + n;
@@ -615,7 +779,7 @@ size_t workspace_bytes(int F, int P, int N, const SlamTrackConfig *cfg, bool hos
     size_t need = lane_bytes(F, P, N, cfg, host);
     if (cfg) {
         int per = 0;
-        for (int n : chunk_sizes(P, cfg->pipeline_chunks, cfg->pipeline_taper_permille)) per = std::max(per, n);
+        for (int n : chunk_sizes(P, planned_chunks(P, N, cfg), cfg->pipeline_taper_permille)) per = std::max(per, n);
         if (per) need = std::max(need, 2 * lane_bytes(per + 1, per, N, cfg, host));
     }
     return need;
@@ -697,6 +861,7 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
     sh.norm = cfg->norm ? cfg->norm : SLAM_NORM_HAMMING2;
     sh.match_mode = cfg->match_mode;
     sh.ratio = cfg->ratio > 0 ? cfg->ratio : 0.6;
+    sh.outputs_pinned = host_pinned(io->h_pose) && host_pinned(io->h_mask);
 
     // ---- plan: the whole shard in one lane on the caller's stream, or chunks pipelined over two side streams ----
     std::vector<Chunk> chunks = plan_chunks(io, cfg);
@@ -732,6 +897,7 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
             return SLAM_E_WORKSPACE;
         }
         L[0].st = st;
+        L[0].match_after = nullptr;
         L[0].set_chunk(sh, 0, P, 0, F);
         int rc = L[0].front(sh);
         if (!rc) rc = L[0].mid(sh);
@@ -755,9 +921,15 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
             SLAM_HIP_CHECK(hipStreamWaitEvent(L[k].st, g_ts.fork, 0));
         }
         const int C = (int)chunks.size();
+        const bool serial = cfg->pipeline_serial_match != 0;
         int rc = SLAM_OK;
+        for (int k = 0; k < 2; ++k) {
+            rc = L[k].ensure_events();                           // lane k's matcher may wait for lane k^1's event
+            if (rc) return rc;
+        }
         for (int c = 0; c < 2 && c < C && !rc; ++c) {
             L[c].set_chunk(sh, chunks[c].a, chunks[c].e, chunks[c].lo, chunks[c].hi);
+            L[c].match_after = serial && c > 0 ? L[c - 1].ev_matched : nullptr;
             rc = L[c].front(sh);
         }
         bool mid_done = false;                                   // mid() of chunk c already ran (see below)
@@ -774,6 +946,7 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
             if (!rc) rc = ln.back(sh);
             if (!rc && c + 2 < C) {
                 ln.set_chunk(sh, chunks[c + 2].a, chunks[c + 2].e, chunks[c + 2].lo, chunks[c + 2].hi);
+                ln.match_after = serial ? L[(c + 1) & 1].ev_matched : nullptr;    // chunk c + 1's matcher, queued earlier
                 rc = ln.front(sh);
             }
         }

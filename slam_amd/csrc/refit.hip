@@ -127,7 +127,9 @@ constexpr int MAX_EVAL = 60;
 template <typename XY4, int RW>
 __global__ __launch_bounds__(RW * 64) void refit_kernel(Mat33 K, const double *X, const XY4 *xy1, const int *count,
                                                         int seg_stride, const unsigned long long *mask_words,
-                                                        const double *pose0, double *pose_out, uint8_t *status, int cap) {
+                                                        const double *pose0, double *pose_out, uint8_t *status, int cap,
+                                                        const int *gate) {
+    if (gate && *gate != 0) return;          // queued speculatively behind a device-side decision that went the other way
     constexpr int RT = RW * 64;
     extern __shared__ double lds[];
     __shared__ double red[RW][28];           // per-wavefront partial sums of one reduction round
@@ -379,7 +381,8 @@ __global__ __launch_bounds__(RW * 64) void refit_kernel(Mat33 K, const double *X
 
 template <typename XY4, int RW>
 int launch_refit_rw(const Mat33 &K, const double *d_X, const XY4 *d_xy1, const int32_t *d_count, int n_seg, int seg_stride,
-                    const uint64_t *d_mask_words, const double *d_pose0, double *d_pose, uint8_t *d_status, hipStream_t st) {
+                    const uint64_t *d_mask_words, const double *d_pose0, double *d_pose, uint8_t *d_status, hipStream_t st,
+                    const int32_t *d_gate) {
     const size_t per = 24 + 2 * sizeof(decltype(XY4::x));       // LDS bytes per supporter
     constexpr size_t LDS_DEFAULT = 60 * 1024, LDS_RAISED = 158 * 1024;   // dynamic part; the kernel's static arrays take < 1 KB of the 64 / 160 KB
     int cap = std::min(seg_stride, seg_stride <= 2048 ? SLAM_REFIT_CAP : 4096);
@@ -400,27 +403,28 @@ int launch_refit_rw(const Mat33 &K, const double *d_X, const XY4 *d_xy1, const i
         }
     }
     hipLaunchKernelGGL((refit_kernel<XY4, RW>), dim3(n_seg), dim3(RW * 64), lds_bytes, st, K, d_X, d_xy1, d_count, seg_stride,
-                       (const unsigned long long *)d_mask_words, d_pose0, d_pose, d_status, cap);
+                       (const unsigned long long *)d_mask_words, d_pose0, d_pose, d_status, cap, d_gate);
     SLAM_HIP_CHECK(hipGetLastError());
     return SLAM_OK;
 }
 
 template <typename XY4>
 int launch_refit_t(const Mat33 &K, const double *d_X, const XY4 *d_xy1, const int32_t *d_count, int n_seg, int seg_stride,
-                   const uint64_t *d_mask_words, const double *d_pose0, double *d_pose, uint8_t *d_status, hipStream_t st) {
-    return launch_refit_rw<XY4, SLAM_REFIT_WAVES>(K, d_X, d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status, st);
+                   const uint64_t *d_mask_words, const double *d_pose0, double *d_pose, uint8_t *d_status, hipStream_t st,
+                    const int32_t *d_gate) {
+    return launch_refit_rw<XY4, SLAM_REFIT_WAVES>(K, d_X, d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status, st, d_gate);
 }
 
 }  // namespace
 
 int slam_launch_refit(const Mat33 &K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count, int n_seg,
                       int seg_stride, const uint64_t *d_mask_words, const double *d_pose0, double *d_pose,
-                      uint8_t *d_status, hipStream_t st) {
+                      uint8_t *d_status, hipStream_t st, const int32_t *d_gate) {
     if (n_seg <= 0) return SLAM_OK;
     SLAM_REQUIRE(seg_stride % 64 == 0, "slam_refit_pnp: seg_stride must be a multiple of 64");
     if (xy_f64)
-        return launch_refit_t(K, d_X, (const double4 *)d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status, st);
-    return launch_refit_t(K, d_X, (const float4 *)d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status, st);
+        return launch_refit_t(K, d_X, (const double4 *)d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status, st, d_gate);
+    return launch_refit_t(K, d_X, (const float4 *)d_xy1, d_count, n_seg, seg_stride, d_mask_words, d_pose0, d_pose, d_status, st, d_gate);
 }
 
 extern "C" int slam_refit_pnp(const double *h_K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count,

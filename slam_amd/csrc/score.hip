@@ -102,7 +102,9 @@ template <typename XY4, int HW, bool RECT>
 __global__ __launch_bounds__(SB) void score_kernel(Mat33 K, Mat34 M2, const double *X, const XY4 *xy1,
                                                    const int *count, const int *seg_of, int n_rows, int groups,
                                                    int seg_stride, const double *pose, const uint8_t *status, int n_hyp,
-                                                   double thr, int *inlier_count, unsigned long long *mask) {
+                                                   double thr, int *inlier_count, unsigned long long *mask,
+                                                   const int *gate) {
+    if (gate && *gate != 0) return;          // queued speculatively behind a device-side decision that went the other way
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  All `groups` workgroups
     // of a segment (they read the same points) therefore go to one XCD: XCD c takes the segments c, c + 8, ...
     // (With the hypothesis group as blockIdx.x every segment's points were fetched by all eight L2s: 1.35 GB of
@@ -348,8 +350,9 @@ int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const 
                       const int32_t *d_count,
                       const int32_t *d_seg_of, int n_rows, int seg_stride, const double *d_pose,
                       const uint8_t *d_status, int n_hyp, double thr, int32_t *d_inlier_count, uint64_t *d_mask,
-                      hipStream_t st) {
+                      hipStream_t st, const int32_t *d_gate) {
     if (n_rows <= 0 || n_hyp <= 0) return SLAM_OK;
+    SLAM_REQUIRE(!d_gate || d_mask, "slam_score_hypotheses: a gate is supported on the mask path only");
     SLAM_REQUIRE(!d_mask || seg_stride % 64 == 0, "slam_score_hypotheses: seg_stride must be a multiple of 64 for masks");
     const bool rect = rectified_rig(K, M2);
     if (!d_mask && n_hyp >= LANES_MIN_HYP) {
@@ -378,7 +381,7 @@ int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const 
     const dim3 grid((unsigned)n_blocks), block(SB);
 #define SLAM_SCORE_LAUNCH(XY, HW, RECT)                                                                                    \
     hipLaunchKernelGGL((score_kernel<XY, HW, RECT>), grid, block, 0, st, K, M2, d_X, (const XY *)d_xy1, d_count, d_seg_of, \
-                       n_rows, groups, seg_stride, d_pose, d_status, n_hyp, thr, d_inlier_count, (unsigned long long *)d_mask)
+                       n_rows, groups, seg_stride, d_pose, d_status, n_hyp, thr, d_inlier_count, (unsigned long long *)d_mask, d_gate)
 #define SLAM_SCORE_LAUNCH_HW(XY, RECT)                                          \
     do {                                                                        \
         if (hw == 2) SLAM_SCORE_LAUNCH(XY, 2, RECT); else SLAM_SCORE_LAUNCH(XY, 1, RECT); \

@@ -347,7 +347,7 @@ def fill_slot(slot: HostSlot, source, first: int, last: int, workers: int = 8) -
 
 
 def track_movie_streamed(source, n_frames_total: int, n_max: int, frames_per_shard: int, cfg: HotPathConfig | None = None,
-                         seed_of_pair=None, n_chunks: int = 2, workers: int = 8, dense_width: int | None = None):
+                         seed_of_pair=None, n_chunks: int = 0, workers: int = 8, dense_width: int | None = None):
     """Whole-movie relative poses (find_features_in_consecutive_frames_whole_movie, utils/utills.py:834-873) for a movie
     that is detected shard by shard: while shard s is tracked on the GPU the host packs and uploads shard s+1.
     seed_of_pair(first_pair, n) -> uint32[n] gives np.random.seed values per pair (default 1000 + pair index).

@@ -54,6 +54,7 @@ def _track_config(cfg: HotPathConfig) -> _lib.SlamTrackConfig:
 class ShardTracker:
     """Owns the device/pinned workspaces for shards of up to (n_frames, n_pairs, n_max) and runs them.
 
+    n_chunks = 0 (default) leaves the plan to the library (two blocks for a large shard, one for a small one);
     n_chunks > 1 asks the library to split the pair list into contiguous blocks and pipeline them over two internal
     HIP streams, so the latency-bound RANSAC rounds (small kernels, host replay, D2H syncs) of one block overlap the
     VALU-bound matching of the next.  Results are identical to n_chunks = 1: every pair's computation is independent
@@ -61,16 +62,18 @@ class ShardTracker:
 
     MAX_PAIRS_PER_CALL = 65535      # slam_track_pairs' limit; run() hands longer pair lists over in blocks of this size
 
-    def __init__(self, n_frames: int, n_pairs: int, n_max: int, cfg: HotPathConfig | None = None, n_chunks: int = 1,
-                 taper: float = 1.0):
+    def __init__(self, n_frames: int, n_pairs: int, n_max: int, cfg: HotPathConfig | None = None, n_chunks: int = 0,
+                 taper: float = 1.0, serial_match: bool | None = None):
         self.cfg = cfg or HotPathConfig()
         self.n_frames, self.n_pairs, self.n_max = n_frames, n_pairs, n_max
         if n_max % 64:
             raise ValueError("n_max must be a multiple of 64")
         self.dev = ops.device()
         self._c = _track_config(self.cfg)
-        self._c.pipeline_chunks = max(1, int(n_chunks))
+        self._c.pipeline_chunks = max(0, int(n_chunks))                # 0: the library's own plan for the shard size
         self._c.pipeline_taper_permille = int(round(1000 * taper))     # each chunk = taper x the previous one
+        # chunks' matchers back to back instead of side by side (None: the default plan)
+        self._c.pipeline_serial_match = int(bool(serial_match)) if serial_match is not None else 0
         L = _lib.lib()
         per_call = min(n_pairs, self.MAX_PAIRS_PER_CALL)          # the workspaces serve one call (one block) at a time
         self.d_ws_bytes = L.slam_track_device_workspace_bytes(n_frames, per_call, n_max, ctypes.byref(self._c))
