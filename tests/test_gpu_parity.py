@@ -634,9 +634,18 @@ def test_refit_on_ill_conditioned_supporter_sets(case):
         assert err <= (REL_TOL if case == "near_planar" else 1e-3), err
 
 
+def _draws_with_repeated_fourth_index(seed, n, draws, slack=8):
+    """Draws of the pair's stream whose fourth index repeats one of the first three (np.random.randint draws with
+    replacement, utils/utills.py:502): AP3P then picks its root by the reprojection error of a point the roots were
+    computed from, i.e. on rounding noise -- in the oracle, in cv2 and here alike -- so the loop's
+    counters may differ on such a pair, as in tests/test_gpu_end_to_end.py."""
+    np.random.seed(int(seed))
+    return sum(int(i[3] in i[:3]) for i in (np.random.randint(0, n, 4) for _ in range(draws + slack)))
+
+
 def test_full_pipeline_against_oracle_sequence():
     from slam_amd.pipeline import ShardTracker, consecutive_pairs
-    seq, desc, xy, count = _small_sequence(n_frames=6, n_features=320, seed=9)
+    seq, desc, xy, count = _small_sequence(n_frames=14, n_features=320, seed=9)
     F, _, n_max, _ = desc.shape
     trk = ShardTracker(F, F - 1, n_max)
     f0, f1 = consecutive_pairs(F)
@@ -648,6 +657,7 @@ def test_full_pipeline_against_oracle_sequence():
         n0, n1 = count[i]
         return dict(dsc_l=desc[i, 0, :n0, :61], dsc_r=desc[i, 1, :n1, :61], xy_l=xy[i, 0, :n0], xy_r=xy[i, 1, :n1])
 
+    clean = 0
     for p in range(F - 1):
         np.random.seed(int(seeds[p]))
         st = {}
@@ -656,13 +666,18 @@ def test_full_pipeline_against_oracle_sequence():
         T = len(want["kp"])
         assert res.stats[p, 0] == T
         assert np.array_equal(kp[p, :T], want["kp"])
+        assert not res.mask[p, T:].any()
+        gt = seq.gt_relative(p + 1)
+        assert np.abs(res.pose[p] - gt).max() < 0.05
+        if _draws_with_repeated_fourth_index(seeds[p], T, max(st["draws"], int(res.stats[p, 3]))):
+            continue                              # a draw decided on rounding noise: tracked set and pose quality only
+        clean += 1
         assert res.stats[p, 2] == st["iterations"] and res.stats[p, 3] == st["draws"] and res.stats[p, 4] == st["best_draw"]
-        assert np.array_equal(res.mask[p, :T], want["mask"]) and not res.mask[p, T:].any()
+        assert np.array_equal(res.mask[p, :T], want["mask"])
         assert res.stats[p, 1] == want["mask"].sum()
         err = np.linalg.norm(res.pose[p] - want["T"]) / np.linalg.norm(want["T"])
         assert err <= REL_TOL, (p, err)
-        gt = seq.gt_relative(p + 1)
-        assert np.abs(res.pose[p] - gt).max() < 0.05
+    assert clean >= 4, clean
 
 
 @pytest.mark.parametrize("how", ["mutual", "knn_ratio"])
@@ -672,8 +687,9 @@ def test_full_pipeline_other_match_methods_against_oracle(how):
     Tracked sets bit-exact against the oracle run with the same matcher; masks and counts equal; poses within REL_TOL."""
     from slam_amd.config import MUTUAL, REGULAR_KNN, HotPathConfig
     from slam_amd.pipeline import ShardTracker, consecutive_pairs
-    seq, desc, xy, count = _small_sequence(n_frames=6, n_features=320, seed=9)
+    seq, desc, xy, count = _small_sequence(n_frames=14, n_features=320, seed=9)
     F, _, n_max, _ = desc.shape
+    clean = 0
     cfg = HotPathConfig(crosscheck_rule=MUTUAL) if how == "mutual" else HotPathConfig(match_method=REGULAR_KNN)
     matcher = orc.bf_match_mutual if how == "mutual" else orc.knn_ratio_match
     f0, f1 = consecutive_pairs(F)
@@ -694,11 +710,15 @@ def test_full_pipeline_other_match_methods_against_oracle(how):
             want = orc.track_pair(frame(p), frame(p + 1), stats=st, matcher=matcher)
         T = len(want["kp"])
         assert res.stats[p, 0] == T and T > 50
-        assert np.array_equal(kp[p, :T], want["kp"])
+        assert np.array_equal(kp[p, :T], want["kp"]) and not res.mask[p, T:].any()
+        if _draws_with_repeated_fourth_index(seeds[p], T, max(st["draws"], int(res.stats[p, 3]))):
+            continue                              # a draw decided on rounding noise (see the helper)
+        clean += 1
         assert res.stats[p, 2] == st["iterations"] and res.stats[p, 3] == st["draws"] and res.stats[p, 4] == st["best_draw"]
-        assert np.array_equal(res.mask[p, :T], want["mask"]) and not res.mask[p, T:].any()
+        assert np.array_equal(res.mask[p, :T], want["mask"])
         err = np.linalg.norm(res.pose[p] - want["T"]) / np.linalg.norm(want["T"])
         assert err <= REL_TOL, (p, err)
+    assert clean >= 4, clean
     # the method really changes the match lists on this data (stats columns 6, 7: stereo / temporal matches per pair;
     # the mutual rule keeps a subset of the legacy rule's pairs, most of the others die in the 4-view join anyway)
     assert not np.array_equal(res.stats[:, 6:8], base.stats[:, 6:8])
