@@ -154,6 +154,24 @@ int slam_triangulate_f64(const double *h_P, const double *h_Q, const double *d_x
  */
 int slam_mt19937_words(uint32_t seed, uint32_t *h_words, int n_words);
 long slam_randint_host(uint32_t seed, uint32_t bound, int32_t *h_out, long n_out);
+
+/* The bookkeeping of the adaptive loop of online_est_pnp_ransac (utils/utills.py:488-491, :498-523), replayed on the
+ * host over hypotheses that were solved and scored in batches: for each draw in [draw_begin, draw_end), in order -- stop
+ * test (outliers_perc != 0, it < log(1 - prob) / log(1 - (1 - outliers_perc)^4), it < max_iterations; or
+ * it < fixed_iterations when that is > 0), a failed solve consumes the draw without counting (:506-507), strict-> best
+ * (:514), cumulative inlier / outlier totals and the clipped outlier ratio (:521-523).  h_status / h_count are indexed by
+ * (draw - draw_begin).  The state carries over from batch to batch; slam_ransac_state_init sets the loop's start values.
+ * Returns 0; st->finished says whether the loop ended inside the batch (st->hit_cap: by the max_draws bound, which the
+ * reference does not have), st->draws how many draws it consumed in all.  Host only; the same code slam_track_pairs uses. */
+typedef struct SlamRansacState {
+    int32_t it, draws, max_supp, best_draw, finished, hit_cap;
+    int64_t inliers, outliers;
+    double outliers_perc;
+    double est_for, est;     /* cache of the iteration estimate */
+} SlamRansacState;
+int slam_ransac_state_init(SlamRansacState *st);
+int slam_ransac_replay(SlamRansacState *st, int n_points, const uint8_t *h_status, const int32_t *h_count, int draw_begin,
+                       int draw_end, double prob, double max_iterations, int fixed_iterations, int max_draws);
 /* The same stream generated on the device, for many pairs at once: for row r,
  *   np.random.seed(d_seed[r]); draws [d_begin[r], d_begin[r] + n_draw) of repeated np.random.randint(0, d_count[r], 4)
  * -> d_sample[r][n_draw][4] (int32).  Rows with d_count[r] <= 0 are left untouched.  Used by the later RANSAC rounds

@@ -47,6 +47,12 @@ class SlamTrackIO(ctypes.Structure):
                 ("h_workspace", c_void_p), ("h_workspace_bytes", c_size_t)]
 
 
+class SlamRansacState(ctypes.Structure):
+    _fields_ = [("it", ctypes.c_int32), ("draws", ctypes.c_int32), ("max_supp", ctypes.c_int32), ("best_draw", ctypes.c_int32),
+                ("finished", ctypes.c_int32), ("hit_cap", ctypes.c_int32), ("inliers", ctypes.c_int64),
+                ("outliers", ctypes.c_int64), ("outliers_perc", c_double), ("est_for", c_double), ("est", c_double)]
+
+
 # name -> (restype, argtypes); must list every symbol include/slam_amd.h declares
 SIGNATURES = {
     "slam_version": (ctypes.c_char_p, []),
@@ -66,6 +72,8 @@ SIGNATURES = {
     "slam_triangulate_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "slam_mt19937_words": (c_int, [c_uint32, c_void_p, c_int]),
     "slam_randint_host": (c_long, [c_uint32, c_uint32, c_void_p, c_long]),
+    "slam_ransac_state_init": (c_int, [c_void_p]),
+    "slam_ransac_replay": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_int, c_int]),
     "slam_randint_draws": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "slam_p3p_hypotheses": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p]),

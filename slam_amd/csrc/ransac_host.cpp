@@ -165,6 +165,43 @@ void RansacReplay::consume(const RansacParams &p, int n_points, const uint8_t *s
     }
 }
 
+// the same replay behind the C ABI, for callers that evaluate hypotheses in batches themselves (the per-pair drop-in)
+extern "C" int slam_ransac_state_init(SlamRansacState *st) {
+    if (!st) {
+        slam_set_error("slam_ransac_state_init: null state");
+        return SLAM_E_INVALID;
+    }
+    const RansacReplay r;
+    st->it = r.it, st->draws = r.draws, st->max_supp = r.max_supp, st->best_draw = r.best_draw;
+    st->finished = 0, st->hit_cap = 0;
+    st->inliers = r.inl, st->outliers = r.outl;
+    st->outliers_perc = r.outliers_perc, st->est_for = r.est_for, st->est = r.est;
+    return SLAM_OK;
+}
+
+extern "C" int slam_ransac_replay(SlamRansacState *st, int n_points, const uint8_t *h_status, const int32_t *h_count,
+                                  int draw_begin, int draw_end, double prob, double max_iterations, int fixed_iterations,
+                                  int max_draws) {
+    if (!st || draw_end < draw_begin || (draw_end > draw_begin && (!h_status || !h_count)) || st->draws < draw_begin) {
+        slam_set_error("slam_ransac_replay: bad arguments (the batch must start at or before the draws consumed so far)");
+        return SLAM_E_INVALID;
+    }
+    RansacReplay r;
+    r.it = st->it, r.draws = st->draws, r.max_supp = st->max_supp, r.best_draw = st->best_draw;
+    r.finished = st->finished != 0, r.hit_cap = st->hit_cap != 0;
+    r.inl = st->inliers, r.outl = st->outliers;
+    r.outliers_perc = st->outliers_perc, r.est_for = st->est_for, r.est = st->est;
+    RansacParams p;
+    p.prob = prob, p.max_iterations = max_iterations, p.fixed_iterations = fixed_iterations;
+    p.max_draws = max_draws > 0 ? max_draws : 0x7fffffff;
+    r.consume(p, n_points, h_status, h_count, draw_begin, draw_end);
+    st->it = r.it, st->draws = r.draws, st->max_supp = r.max_supp, st->best_draw = r.best_draw;
+    st->finished = r.finished, st->hit_cap = r.hit_cap;
+    st->inliers = r.inl, st->outliers = r.outl;
+    st->outliers_perc = r.outliers_perc, st->est_for = r.est_for, st->est = r.est;
+    return SLAM_OK;
+}
+
 // ---- convert_trans_from_rel_to_global (utils/utills.py:749-757): running composition T_i @ [T_{i-1..0}; 0 0 0 1] ----
 // numpy evaluates `second @ hom(first)` through BLAS dgemm: k ascending, fused multiply-adds from a zero accumulator.
 extern "C" int slam_compose_global(const double *h_rel, int n, double *h_global) {

@@ -370,6 +370,186 @@ class _LazyObjects:
         return self[:]
 
 
+class _Unset:
+    """What a lazily materialised object array holds in a slot nobody has asked for yet.  Reading the array itself (an
+    index, a slice, a mask, iteration, tolist, copy, pickle) never shows it; a RAW numpy copy of the buffer made behind
+    the array's back (np.array(a), np.asarray(a), a.view(np.ndarray)) does, and using such an element fails loudly."""
+    __slots__ = ()
+
+    def __getattr__(self, name):
+        raise RuntimeError("element of a lazily materialised array reached through a raw numpy copy of its buffer "
+                           "(np.array / np.asarray of the array): index or iterate the array itself, or call "
+                           ".materialise() on it first")
+
+    def __repr__(self):
+        return "<not materialised>"
+
+
+_UNSET = _Unset()
+
+
+class LazyObjectArray(np.ndarray):
+    """A real 1-D numpy object array (isinstance np.ndarray, dtype object -- what the reference's callers get from
+    np.array(list of cv2 objects), utils/utills.py:54,110,975) whose elements are made on first access from index /
+    coordinate arrays kept beside it.  The reference's per-pair functions hand thousands of KeyPoint / DMatch / Feature
+    objects from one to the next and read a few fields of each; building them eagerly cost 3 ms per frame pair around
+    tens of microseconds of device work.  The hot-path functions of slam_amd.utills read the arrays underneath when
+    they are handed one of these, and everything else sees ordinary objects.
+
+    Subclasses set `_n` arrays and implement `_make(idx) -> list of objects` and `_subset(idx) -> same type`."""
+
+    def __new__(cls, n):
+        a = np.empty(int(n), dtype=object).view(cls)
+        np.ndarray.fill(a, _UNSET)
+        a._filled = np.zeros(int(n), bool)
+        return a
+
+    def __array_finalize__(self, parent):
+        # arrays numpy derives behind our back (views, copies) carry no recipe: their unset slots stay loud (_Unset)
+        self._filled = None
+
+    # -- materialisation --
+    def _fill(self, idx):
+        if self._filled is None:
+            return
+        idx = np.atleast_1d(idx)
+        need = idx[~self._filled[idx]]
+        if len(need):
+            raw = self.view(np.ndarray)
+            for i, o in zip(need.tolist(), self._make(need)):
+                raw[i] = o
+            self._filled[need] = True
+
+    def materialise(self):
+        """The same array with every element made: a plain numpy object array sharing this one's memory."""
+        if self._filled is not None and not self._filled.all():
+            self._fill(np.nonzero(~self._filled)[0])
+        return self.view(np.ndarray)
+
+    # -- everything that reads elements goes through here --
+    def __getitem__(self, key):
+        if self._filled is None:
+            return np.ndarray.__getitem__(self, key)
+        if isinstance(key, (int, np.integer)):
+            i = int(key)
+            if i < 0:
+                i += len(self)
+            if not 0 <= i < len(self):
+                raise IndexError(f"index {key} is out of bounds for axis 0 with size {len(self)}")
+            if not self._filled[i]:
+                self._fill(i)
+            return np.ndarray.__getitem__(self.view(np.ndarray), i)
+        if isinstance(key, slice):
+            idx = np.arange(*key.indices(len(self)))
+        else:
+            k = np.asarray(key)
+            if k.dtype == bool:
+                if k.shape != (len(self),):
+                    raise IndexError("boolean index did not match the array")
+                idx = np.nonzero(k)[0]
+            elif k.ndim == 1 and k.dtype.kind in "iu":
+                idx = np.where(k < 0, k + len(self), k).astype(np.int64)
+                if len(idx) and (idx.min() < 0 or idx.max() >= len(self)):
+                    raise IndexError("index out of bounds")
+            elif k.ndim == 1 and k.size == 0:
+                idx = np.zeros(0, np.int64)
+            else:                                   # anything exotic: plain numpy semantics on the materialised array
+                return self.materialise()[key]
+        return self._subset(idx)
+
+    def __iter__(self):
+        return iter(self.materialise())
+
+    def __setitem__(self, key, value):
+        self.materialise()[key] = value
+
+    def tolist(self):
+        return self.materialise().tolist()
+
+    def copy(self, order="C"):
+        return self.materialise().copy(order)
+
+    def __reduce__(self):
+        return self.materialise().__reduce__()     # pickles as the plain object array it stands for
+
+    def __array_function__(self, func, types, args, kwargs):
+        # numpy functions (concatenate, array_equal, ...) see the materialised arrays
+        def plain(x):
+            if isinstance(x, LazyObjectArray):
+                return x.materialise()
+            if isinstance(x, (list, tuple)):
+                return type(x)(plain(v) for v in x)
+            return x
+        return func(*plain(args), **{k: plain(v) for k, v in kwargs.items()})
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        inputs = tuple(x.materialise() if isinstance(x, LazyObjectArray) else x for x in inputs)
+        if "out" in kwargs:
+            kwargs["out"] = tuple(x.materialise() if isinstance(x, LazyObjectArray) else x for x in kwargs["out"])
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
+    def __repr__(self):
+        done = "?" if self._filled is None else int(self._filled.sum())
+        return f"<{type(self).__name__} of {len(self)} ({done} materialised)>"
+
+    __str__ = __repr__
+
+
+class KeyPointArray(LazyObjectArray):
+    """KeyPoint objects over float32 coordinates `xy` [n, 2] (np.array(alg.detectAndCompute(...)[0]), utills.py:54)."""
+
+    def __new__(cls, xy):
+        xy = np.ascontiguousarray(np.asarray(xy, dtype=np.float32).reshape(-1, 2))
+        a = super().__new__(cls, len(xy))
+        a.xy = xy
+        return a
+
+    def _make(self, idx):
+        out, new = [], KeyPoint.__new__
+        for pt in self.xy[idx].astype(np.float64).tolist():
+            k = new(KeyPoint)
+            k.pt = (pt[0], pt[1])
+            out.append(k)
+        return out
+
+    def _subset(self, idx):
+        return KeyPointArray(self.xy[idx])
+
+
+class DMatchArray(LazyObjectArray):
+    """DMatch objects over (queryIdx, trainIdx, distance) arrays (np.array(matcher.match(...)), utills.py:110)."""
+
+    def __new__(cls, q, t, d):
+        q = np.asarray(q, dtype=np.int64).reshape(-1)
+        a = super().__new__(cls, len(q))
+        a.q, a.t, a.d = q, np.asarray(t, dtype=np.int64).reshape(-1), np.asarray(d, dtype=np.float64).reshape(-1)
+        return a
+
+    def _make(self, idx):
+        return dmatches_from_arrays(self.q[idx], self.t[idx], self.d[idx]).tolist()
+
+    def _subset(self, idx):
+        return DMatchArray(self.q[idx], self.t[idx], self.d[idx])
+
+
+class FeatureArray(LazyObjectArray):
+    """Feature objects (utills.py:963-975) over key-point index pairs `kp` int[n, 2] (left, right) and coordinates `coor`
+    float32[n, 4] (x_left, y_left, x_right, y_right)."""
+
+    def __new__(cls, kp, coor):
+        kp = np.asarray(kp, dtype=np.int64).reshape(-1, 2)
+        a = super().__new__(cls, len(kp))
+        a.kp, a.coor = kp, np.asarray(coor, dtype=np.float32).reshape(-1, 4)
+        return a
+
+    def _make(self, idx):
+        return [Feature(k[0], k[1], c[0], c[2], c[1], c[3])
+                for k, c in zip(self.kp[idx].tolist(), self.coor[idx].astype(np.float64).tolist())]
+
+    def _subset(self, idx):
+        return FeatureArray(self.kp[idx], self.coor[idx])
+
+
 class LazyPairFeatures(_LazyObjects):
     """`consecutive_frame_features` of the whole-movie driver (utils/utills.py:867: one [frame-i features, frame-(i+1)
     features] entry per pair) kept as the supporters' key-point index arrays; entry i becomes two object arrays of

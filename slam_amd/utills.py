@@ -19,14 +19,16 @@ Differences a caller can observe, all forced by the environment:
 """
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 import torch
 
 from . import _lib, ops, pipeline, tracks, trajectory
 from .config import BRUTE_FORCE, FLANN_KNN, MUTUAL, NORM_HAMMING, NORM_HAMMING2, OCV_LEGACY, REGULAR_KNN, HotPathConfig
 from .synth import K_KITTI, M1_KITTI, M2_KITTI
-from .types import (ArrayDataBase, DataBase, DMatch, Feature, Frame, KeyPoint, LazyPairFeatures, Track, dmatches_from_arrays,
-                    keypoints_from_xy, keypoints_to_xy)
+from .types import (ArrayDataBase, DataBase, DMatch, DMatchArray, Feature, FeatureArray, Frame, KeyPoint, KeyPointArray,
+                    LazyPairFeatures, Track, dmatches_from_arrays, keypoints_from_xy, keypoints_to_xy)
 
 # == module constants, as utills.py:17-42 ==
 K, M1, M2 = K_KITTI.copy(), M1_KITTI.copy(), M2_KITTI.copy()
@@ -97,6 +99,53 @@ def _match_arrays(img1_dsc, img2_dsc, norm, mode):
     return i1, d1, i2, d2
 
 
+class DescriptorArray(np.ndarray):
+    """The descriptor matrix read_and_rec_match returns (np.array(dsc), utills.py:54): an ordinary uint8[n, d] array
+    that remembers the padded copy of itself already on the device (`_dev`), so the temporal match of the next call
+    does not upload it again."""
+
+    def __new__(cls, dsc, dev=None):
+        a = np.asarray(dsc).view(cls)
+        a._dev = dev
+        return a
+
+    def __array_finalize__(self, parent):
+        self._dev = None                      # slices, copies: a different matrix
+
+
+def _dev_descriptors(dsc):
+    dev = getattr(dsc, "_dev", None)
+    return dev if dev is not None else _cuda(ops.pad_descriptors(dsc))
+
+
+def _match_qtd(img1_dsc, img2_dsc, method=None):
+    """match() (:105-119) as arrays: (queryIdx, trainIdx, distance) of the matches in query order, under MATCHES_NORM and
+    the method's rule (cross-check, or kNN + ratio test in float64 as significance_test evaluates it)."""
+    method = MATCH_METHOD if method is None else method
+    nq = len(img1_dsc)
+    if method not in (BRUTE_FORCE, REGULAR_KNN) or nq == 0 or len(img2_dsc) == 0:
+        if method == FLANN_KNN:
+            knn_flann_matching(img1_dsc, img2_dsc)
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float64)
+    q, t = _dev_descriptors(img1_dsc), _dev_descriptors(img2_dsc)
+    if method == BRUTE_FORCE:
+        mode = _lib.SLAM_MATCH_CROSSCHECK_MUTUAL if CROSSCHECK_RULE == MUTUAL else _lib.SLAM_MATCH_CROSSCHECK
+        k1, _ = ops.match_keys(q, t, MATCHES_NORM, mode)
+        k1 = k1.cpu().numpy().view(np.uint32)
+        keep = np.nonzero(k1 != _lib.SLAM_KEY_NONE)[0]
+    else:
+        k1, k2 = ops.match_keys(q, t, MATCHES_NORM, _lib.SLAM_MATCH_KNN2)
+        k12 = torch.stack([k1, k2]).cpu().numpy().view(np.uint32)
+        k1, k2 = k12[0], k12[1]
+        both = (k1 != _lib.SLAM_KEY_NONE) & (k2 != _lib.SLAM_KEY_NONE)        # significance_test unpacks two neighbours
+        if not both.all() and (k1 != _lib.SLAM_KEY_NONE).any():
+            raise ValueError("not enough values to unpack (expected 2, got 1)")       # a train image with one row (:137)
+        d1, d2 = (k1 >> _lib.SLAM_KEY_SHIFT).astype(np.float64), (k2 >> _lib.SLAM_KEY_SHIFT).astype(np.float64)
+        keep = np.nonzero(both & (d1 < RATIO * d2))[0]
+    k = k1[keep]
+    return keep.astype(np.int64), (k & ops.IDX_MASK).astype(np.int64), (k >> _lib.SLAM_KEY_SHIFT).astype(np.float64)
+
+
 def bf_matching(metric, img1_dsc, img2_dsc, crossCheck=True, sort=True):
     """:57-70.  cv2.BFMatcher(metric, crossCheck).match: list of DMatch in query order, or sorted by distance."""
     if crossCheck:
@@ -155,9 +204,13 @@ def match(img1_dsc, img2_dsc, method=None):
 
 
 def detect_and_match(img1, img2):
-    """:122-128 with detection replaced by the detection source: img = (xy, dsc)."""
+    """:122-128 with detection replaced by the detection source: img = (xy, dsc).  The key-point and match arrays are
+    numpy object arrays, as the reference's, whose KeyPoint / DMatch elements are made when they are read
+    (types.LazyObjectArray); the functions below work on the coordinate / index arrays underneath."""
     (xy1, dsc1), (xy2, dsc2) = img1, img2
-    return keypoints_from_xy(xy1), np.array(dsc1), keypoints_from_xy(xy2), np.array(dsc2), match(dsc1, dsc2)
+    d1 = DescriptorArray(dsc1, _cuda(ops.pad_descriptors(dsc1)))
+    d2 = DescriptorArray(dsc2, _cuda(ops.pad_descriptors(dsc2)))
+    return KeyPointArray(xy1), d1, KeyPointArray(xy2), d2, DMatchArray(*_match_qtd(d1, d2))
 
 
 # == Ex2: stereo-row rejection, triangulation ==
@@ -170,6 +223,10 @@ def axes_of_matches(match, img1_kpts, img2_kpts):
 
 def rectified_stereo_pattern_rej(img1_kpts, img2_kpts, matches):
     """:168-183.  |y_right - y_left| <= REC_ERR, inclusive; returns index lists into `matches`."""
+    if isinstance(matches, DMatchArray) and isinstance(img1_kpts, KeyPointArray) and isinstance(img2_kpts, KeyPointArray):
+        # float32 coordinates widened to float64, as KeyPoint.pt hands them out
+        ok = np.abs(img2_kpts.xy[matches.t, 1].astype(np.float64) - img1_kpts.xy[matches.q, 1].astype(np.float64)) <= REC_ERR
+        return np.nonzero(ok)[0].tolist(), np.nonzero(~ok)[0].tolist()
     inl, outl = [], []
     for i in range(len(matches)):
         _, y1, _, y2 = axes_of_matches(matches[i], img1_kpts, img2_kpts)
@@ -219,6 +276,17 @@ def find_kpts_in_all_4_rec(left0_left1_matches, rec0_dic, rec1_dic):
 
 def tracking_4images(left0_dsc, left1_dsc, pair0_matches, pair0_rec_matches_idx, pair1_matches, pair1_rec_matches_idx):
     """:945-960."""
+    if isinstance(pair0_matches, DMatchArray) and isinstance(pair1_matches, DMatchArray):
+        # the same dictionaries and scan as below, on the index arrays (a later duplicate key overwrites, as in a dict)
+        tq, tt, _ = _match_qtd(left0_dsc, left1_dsc)
+        r0, r1 = np.asarray(pair0_rec_matches_idx, dtype=np.int64), np.asarray(pair1_rec_matches_idx, dtype=np.int64)
+        tab0 = np.full(max(len(left0_dsc), 1), -1, np.int64)
+        tab1 = np.full(max(len(left1_dsc), 1), -1, np.int64)
+        tab0[pair0_matches.q[r0]] = r0
+        tab1[pair1_matches.q[r1]] = r1
+        i0, i1 = tab0[tq], tab1[tt]
+        keep = (i0 >= 0) & (i1 >= 0)
+        return pair0_matches[i0[keep]], pair1_matches[i1[keep]]
     left0_left1_matches = match(left0_dsc, left1_dsc)
     rec0 = create_rec_dic(pair0_matches, pair0_rec_matches_idx)
     rec1 = create_rec_dic(pair1_matches, pair1_rec_matches_idx)
@@ -280,7 +348,7 @@ def find_supporters_4_frame(pair0_p3d_pts, left1_proj_mat, left1_matches_coor, r
 
 
 class _Device4View:
-    """Points of one frame pair on the device in the batched layout (one segment, float64 observations)."""
+    """Points of one frame pair on the device in the batched layout (one segment)."""
 
     def __init__(self, world, left1, right1):
         X, l, r = _as_f64_points(world, left1, right1)
@@ -294,11 +362,56 @@ class _Device4View:
         self.X, self.xy = _cuda(Xs), _cuda(xy)
         self.count = _cuda(np.array([self.n], np.int32))
 
+    @classmethod
+    def on_device(cls, X, xy, count, n):
+        """X float64[1, stride, 3], xy float32 | float64 [1, stride, 4], count int32[1] already on the device."""
+        v = cls.__new__(cls)
+        v.n, v.stride, v.X, v.xy, v.count = int(n), int(X.shape[1]), X, xy, count
+        return v
+
 
 def _iter_estimate(prob, outliers_perc, model_parm_num):
     """:488-489."""
     with np.errstate(divide="ignore", invalid="ignore"):
         return np.log(1 - prob) / np.log(1 - np.power(1 - outliers_perc, model_parm_num))
+
+
+def _ransac_global_stream(pts, right1_to_left1_ex_mat, calib_mat, thr, model_parm_num=PNP_NUM_PTS):
+    """The loop of :498-523 + :526-530 over points already on the device, drawing from the GLOBAL np.random stream in
+    chunks; the loop's bookkeeping is replayed over each chunk by the library (slam_ransac_replay, the code the shard
+    pipeline uses) and the stream is rewound to exactly the draws the reference would have consumed."""
+    n = pts.n
+    L = _lib.lib()
+    st = _lib.SlamRansacState()
+    L.slam_ransac_state_init(ctypes.byref(st))
+    state = np.random.get_state()
+    prob, max_iterations = 0.9999, 1e3
+    best_pose, chunk, begin = None, 64, 0
+    while not st.finished:
+        sample = np.random.randint(0, n, (chunk, model_parm_num)).astype(np.int32)
+        pose, status = ops.p3p_hypotheses(calib_mat, pts.X, pts.xy, pts.count, _cuda(sample[None]))
+        cnt, _ = ops.score_hypotheses(calib_mat, right1_to_left1_ex_mat, pts.X, pts.xy, pts.count, pose, status, thr)
+        h_status, h_cnt = np.ascontiguousarray(status.cpu().numpy()[0]), np.ascontiguousarray(cnt.cpu().numpy()[0])
+        before = st.best_draw
+        _lib.check(L.slam_ransac_replay(ctypes.byref(st), n, h_status.ctypes.data, h_cnt.ctypes.data, begin, begin + chunk,
+                                        prob, max_iterations, 0, MAX_DRAWS))
+        if st.hit_cap:
+            raise RuntimeError(f"no PnP-RANSAC termination within {MAX_DRAWS} draws (the reference would not return)")
+        if st.best_draw != before:
+            best_pose = pose[0, st.best_draw - begin].clone()
+        begin += chunk
+        chunk = min(chunk * 4, 4096)
+    np.random.set_state(state)                                   # leave the stream where the reference would
+    if st.draws:
+        np.random.randint(0, n, (st.draws, model_parm_num))
+    if best_pose is None:
+        raise TypeError("'NoneType' object is not iterable")     # sum(None) in extra_refine (:558)
+    one = torch.ones((1, 1), dtype=torch.uint8, device=pts.X.device)
+    _, words = ops.score_hypotheses(calib_mat, right1_to_left1_ex_mat, pts.X, pts.xy, pts.count, best_pose[None, None],
+                                    one, thr, want_mask=True)
+    T, status = ops.refit_pnp(calib_mat, pts.X, pts.xy, pts.count, words[0], best_pose[None])
+    mask = ops.mask_words_to_bool(words.cpu().numpy()[0, 0], n)
+    return (T.cpu().numpy()[0] if int(status[0]) else None), mask
 
 
 def online_est_pnp_ransac(model_parm_num, world_p3d_pts, left0_ex_mat, left0_matches_coor, right0_ex_mat,
@@ -315,54 +428,37 @@ def online_est_pnp_ransac(model_parm_num, world_p3d_pts, left0_ex_mat, left0_mat
     if n == 0:
         np.random.randint(0, 0, model_parm_num)                 # raises ValueError like the reference (:502)
     pts = _Device4View(world_p3d_pts, left1_matches_coor, right1_matches_coor)
-    thr = acc ** 2
-    state = np.random.get_state()
-    prob, outliers_perc, max_iterations = 0.9999, 0.99, 1e3
-    it = draws = inl = outl = 0
-    max_supp, best_pose = -1, None
-    chunk, done = 64, False
-    while not done:
-        sample = np.random.randint(0, n, (chunk, model_parm_num)).astype(np.int32)
-        pose, status = ops.p3p_hypotheses(calib_mat, pts.X, pts.xy, pts.count, _cuda(sample[None]))
-        cnt, _ = ops.score_hypotheses(calib_mat, right1_to_left1_ex_mat, pts.X, pts.xy, pts.count, pose, status, thr)
-        status, cnt = status.cpu().numpy()[0], cnt.cpu().numpy()[0]
-        best_here = -1
-        for k in range(chunk):
-            if not (outliers_perc != 0 and it < _iter_estimate(prob, outliers_perc, model_parm_num)
-                    and it < max_iterations):
-                done = True
-                break
-            if draws >= MAX_DRAWS:
-                raise RuntimeError(f"no PnP-RANSAC termination within {MAX_DRAWS} draws (the reference would not return)")
-            draws += 1
-            if not status[k]:
-                continue                                          # :506-507
-            num = int(cnt[k])
-            if num > max_supp:
-                max_supp, best_here = num, k
-            it += 1
-            outl += n - num
-            inl += num
-            outliers_perc = min(outl / (inl + outl), 0.99)
-        if best_here >= 0:
-            best_pose = pose[0, best_here].clone()
-        chunk = min(chunk * 4, 4096)
-    np.random.set_state(state)                                   # leave the stream where the reference would
-    if draws:
-        np.random.randint(0, n, (draws, model_parm_num))
-    if best_pose is None:
-        raise TypeError("'NoneType' object is not iterable")     # sum(None) in extra_refine (:558)
-    one = torch.ones((1, 1), dtype=torch.uint8, device=pts.X.device)
-    _, words = ops.score_hypotheses(calib_mat, right1_to_left1_ex_mat, pts.X, pts.xy, pts.count, best_pose[None, None],
-                                    one, thr, want_mask=True)
-    mask = ops.mask_words_to_bool(words.cpu().numpy()[0, 0], n)
-    T, status = ops.refit_pnp(calib_mat, pts.X, pts.xy, pts.count, words[0], best_pose[None])
-    return (T.cpu().numpy()[0] if int(status[0]) else None), mask
+    return _ransac_global_stream(pts, right1_to_left1_ex_mat, calib_mat, acc ** 2, model_parm_num)
+
+
+def _dlt_pose(world, img, calib_mat):
+    """The start cv2.solvePnP(flags=SOLVEPNP_ITERATIVE) gives its Levenberg-Marquardt solver for a non-planar set
+    (cvFindExtrinsicCameraParams2, called at :592 through :562-563): the 12 entries of [R|t] as the null vector of the
+    2n x 12 DLT system on K-normalised image points, the rotation part projected onto SO(3) (U V^T of its SVD) and the
+    translation rescaled by the same factor.  A 12 x 12 eigenproblem: host numpy, like the reference's own glue."""
+    fx, fy, cx, cy = calib_mat[0][0], calib_mat[1][1], calib_mat[0][2], calib_mat[1][2]
+    n = len(world)
+    mx, my = (img[:, 0] - cx) / fx, (img[:, 1] - cy) / fy
+    L = np.zeros((2 * n, 12))
+    L[0::2, 0:3], L[0::2, 3] = world, 1.0
+    L[0::2, 8:11], L[0::2, 11] = -mx[:, None] * world, -mx
+    L[1::2, 4:7], L[1::2, 7] = world, 1.0
+    L[1::2, 8:11], L[1::2, 11] = -my[:, None] * world, -my
+    _, _, Vt = np.linalg.svd(L.T @ L)
+    RRt = Vt[11].reshape(3, 4)
+    if np.linalg.det(RRt[:, :3]) < 0:
+        RRt = -RRt
+    U, _, Vt2 = np.linalg.svd(RRt[:, :3])
+    R = U @ Vt2
+    t = RRt[:, 3] * (np.linalg.norm(R) / np.linalg.norm(RRt[:, :3]))
+    return np.hstack((R, t.reshape(3, 1)))
 
 
 def pnp(world_p3d_pts, img_proj_coor, calib_mat, flag, init=None):
-    """:585-596.  [R|t] 3x4 or None.  flag = SOLVEPNP_AP3P (4 points) or SOLVEPNP_ITERATIVE (>= 6 points; the
-    Levenberg-Marquardt refit starts from `init` or, without one, from the best of a few AP3P poses)."""
+    """:585-596.  [R|t] 3x4 or None.  flag = SOLVEPNP_AP3P (exactly 4 points; None when AP3P has no root) or
+    SOLVEPNP_ITERATIVE (>= 6 points: the DLT start of cv2's solver, _dlt_pose, or `init` when the caller has a pose --
+    the RANSAC winner in the hot path -- then the Levenberg-Marquardt refit on the device; like cv2 it returns a pose
+    for any >= 6 points, and None below that as the caller's guard at :558-559 expects)."""
     world = np.asarray(world_p3d_pts, dtype=np.float64).reshape(-1, 3)
     img = np.asarray(img_proj_coor, dtype=np.float64).reshape(-1, 2)
     pts = _Device4View(world, img, img)
@@ -375,16 +471,9 @@ def pnp(world_p3d_pts, img_proj_coor, calib_mat, flag, init=None):
     if n < 6:
         return None
     if init is None:
-        j = np.arange(min(32, n))
-        sample = np.stack([j, (j + n // 4) % n, (j + n // 2) % n, (j + 3 * n // 4) % n], 1).astype(np.int32)
-        pose, status = ops.p3p_hypotheses(calib_mat, pts.X, pts.xy, pts.count, _cuda(sample[None]))
-        cnt, _ = ops.score_hypotheses(calib_mat, M1, pts.X, pts.xy, pts.count, pose, status, float(SUPP_ERR ** 2))
-        cnt = cnt.cpu().numpy()[0] * status.cpu().numpy()[0]
-        if cnt.max() <= 0:
-            return None
-        init_t = pose[0, int(np.argmax(cnt))][None]
-    else:
-        init_t = _cuda(np.asarray(init, dtype=np.float64).reshape(1, 3, 4))
+        with np.errstate(all="ignore"):
+            init = _dlt_pose(world, img, np.asarray(calib_mat, dtype=np.float64))
+    init_t = _cuda(np.asarray(init, dtype=np.float64).reshape(1, 3, 4))
     words = _cuda(ops.bool_to_mask_words(np.ones((1, n), bool), pts.stride))
     T, status = ops.refit_pnp(calib_mat, pts.X, pts.xy, pts.count, words, init_t)
     return T.cpu().numpy()[0] if int(status[0]) else None
@@ -484,6 +573,8 @@ def trajectory_error_summary(db, ground_truth, delta=1):
 # == Ex4: per-pair and whole-movie drivers ==
 def get_feature_obj(matches, img1_kpts, img2_kpts):
     """:963-975."""
+    if isinstance(matches, DMatchArray) and isinstance(img1_kpts, KeyPointArray) and isinstance(img2_kpts, KeyPointArray):
+        return FeatureArray(np.stack([matches.q, matches.t], 1), np.hstack([img1_kpts.xy[matches.q], img2_kpts.xy[matches.t]]))
     out = np.empty(len(matches), dtype=object)
     for i, m in enumerate(matches):
         (x1, y1), (x2, y2) = img1_kpts[m.queryIdx].pt, img2_kpts[m.trainIdx].pt
@@ -493,11 +584,15 @@ def get_feature_obj(matches, img1_kpts, img2_kpts):
 
 def get_features_left_coor(frame_features):
     """:978-986."""
+    if isinstance(frame_features, FeatureArray):
+        return frame_features.coor[:, 0:2].astype(np.float64) if len(frame_features) else np.array([])
     return np.array([f.get_left_coor() for f in frame_features])
 
 
 def get_features_right_coor(frame_features):
     """:989-997."""
+    if isinstance(frame_features, FeatureArray):
+        return frame_features.coor[:, 2:4].astype(np.float64) if len(frame_features) else np.array([])
     return np.array([f.get_right_coor() for f in frame_features])
 
 
@@ -514,6 +609,10 @@ def read_and_rec_match(frame_num):
 def find_features_in_consecutive_frames(left0_kpts, left0_dsc, right0_kpts, pair0_matches, pair0_rec_matches_idx,
                                         left1_kpts, left1_dsc, right1_kpts, pair1_matches, pair1_rec_matches_idx):
     """:876-925.  -> (pose, frame0 features, frame1 features, inlier %, supporter mask)."""
+    if all(isinstance(k, KeyPointArray) for k in (left0_kpts, right0_kpts, left1_kpts, right1_kpts)) and \
+            isinstance(pair0_matches, DMatchArray) and isinstance(pair1_matches, DMatchArray):
+        return _consecutive_frames_on_arrays(left0_kpts, left0_dsc, right0_kpts, pair0_matches, pair0_rec_matches_idx,
+                                             left1_kpts, left1_dsc, right1_kpts, pair1_matches, pair1_rec_matches_idx)
     t0, t1 = tracking_4images(left0_dsc, left1_dsc, pair0_matches, pair0_rec_matches_idx, pair1_matches,
                               pair1_rec_matches_idx)
     frame0_features = get_feature_obj(t0, left0_kpts, right0_kpts)
@@ -523,6 +622,30 @@ def find_features_in_consecutive_frames(left0_kpts, left0_dsc, right0_kpts, pair
     left1, right1 = get_features_left_coor(frame1_features), get_features_right_coor(frame1_features)
     trans, mask = online_est_pnp_ransac(PNP_NUM_PTS, X, M1, left0, M2, right0, left1, M2, right1, K, acc=SUPP_ERR)
     perc = 100 * sum(mask) / len(mask)
+    return trans, frame0_features, frame1_features, perc, mask
+
+
+def _consecutive_frames_on_arrays(left0_kpts, left0_dsc, right0_kpts, pair0_matches, pair0_rec_matches_idx,
+                                  left1_kpts, left1_dsc, right1_kpts, pair1_matches, pair1_rec_matches_idx):
+    """find_features_in_consecutive_frames (:876-925) when the key-point / match arrays are the lazily materialised ones
+    read_and_rec_match hands out: the same steps in the same order (:890-923), on the coordinate / index arrays
+    underneath, with the triangulated points staying on the device between triangulation and the RANSAC loop."""
+    t0, t1 = tracking_4images(left0_dsc, left1_dsc, pair0_matches, pair0_rec_matches_idx, pair1_matches,
+                              pair1_rec_matches_idx)
+    frame0_features = get_feature_obj(t0, left0_kpts, right0_kpts)
+    frame1_features = get_feature_obj(t1, left1_kpts, right1_kpts)
+    n = len(frame0_features)
+    if n == 0:
+        np.random.randint(0, 0, PNP_NUM_PTS)                    # raises ValueError like the reference (:502)
+    stride = max(64, (n + 63) // 64 * 64)
+    xy = np.zeros((2, stride, 4), np.float32)                   # segment 0: frame 0 (for triangulation), segment 1: frame 1
+    xy[0, :n], xy[1, :n] = frame0_features.coor, frame1_features.coor
+    d_xy = _cuda(xy)
+    count = _cuda(np.array([n], np.int32))
+    X = ops.triangulate(K @ M1, K @ M2, d_xy[0:1], count)
+    pts = _Device4View.on_device(X, d_xy[1:2], count, n)
+    trans, mask = _ransac_global_stream(pts, M2, K, SUPP_ERR ** 2)
+    perc = 100 * mask.sum() / len(mask)                         # :923; numpy int / int, as sum() of a bool array gives
     return trans, frame0_features, frame1_features, perc, mask
 
 

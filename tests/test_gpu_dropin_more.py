@@ -137,3 +137,36 @@ def test_loop_candidates_of_many_current_frames_in_one_pass(golden, movie):
     assert U.find_loop_cands_by_consensus_batch([], [], [], 50.0) == []
     with pytest.raises(ValueError):
         U.find_loop_cands_by_consensus_batch([[1]], [[1], [2]], [3], 50.0)
+
+
+def test_iterative_pnp_without_a_start_follows_the_reference(golden_more):
+    """utills.pnp(..., SOLVEPNP_ITERATIVE) and extra_refine called WITHOUT `init`, as the reference calls them
+    (:562-563, :592): cv2's ITERATIVE solver starts from a DLT pose and returns a pose for any >= 6 points.  Held to the
+    oracle's restatement of it within 1e-5 relative (both end in the same minimum of the left reprojection error), on
+    inlier sets of RANSAC-like problems and on the golden few-supporter case; and never None for >= 6 points."""
+    import slam_oracle as orc
+    rng = np.random.default_rng(11)
+    T0 = np.hstack([orc.rodrigues_vec_to_mat(np.array([0.01, -0.03, 0.005])), np.array([[0.05], [-0.02], [-0.8]])])
+    for n in (6, 7, 40, 500):
+        X = np.stack([rng.uniform(-20, 20, n), rng.uniform(-4, 3, n), rng.uniform(4, 70, n)], 1)
+        l = (orc.project(X, U.K @ T0) + rng.normal(0, 0.3, (n, 2))).astype(np.float32).astype(np.float64)
+        r = (orc.project(X, U.K @ orc.compose(T0, U.M2)) + rng.normal(0, 0.3, (n, 2))).astype(np.float32).astype(np.float64)
+        with np.errstate(all="ignore"):
+            want = orc.pnp(X, l, U.K, orc.SOLVEPNP_ITERATIVE)
+        got = U.pnp(X, l, U.K, U.SOLVEPNP_ITERATIVE)
+        assert got is not None and want is not None
+        assert _close(got, want), (n, np.linalg.norm(got - want) / np.linalg.norm(want))
+        mask = np.ones(n, bool)
+        mask[::5] = n < 10                                        # leave some points out of the refit (when there are enough)
+        T, new_mask = U.extra_refine(mask, X, l, U.M2, r, U.K, acc=2)
+        with np.errstate(all="ignore"):
+            want_T, want_mask = orc.extra_refine(mask, X, l, U.M2, r, U.K, 2)
+        assert _close(T, want_T) and np.array_equal(np.asarray(new_mask, bool), np.asarray(want_mask, bool))
+    # a spread that no AP3P sample explains (pure noise): cv2 still returns a pose; so does this
+    X = rng.uniform(-5, 5, (12, 3)) + [0, 0, 20]
+    assert U.pnp(X, rng.uniform(0, 1000, (12, 2)), U.K, U.SOLVEPNP_ITERATIVE) is not None
+    assert U.pnp(X[:5], rng.uniform(0, 1000, (5, 2)), U.K, U.SOLVEPNP_ITERATIVE) is None
+    # the golden few-supporter case (:558-559): fewer than 6 supporters -> (None, all False), whatever the start
+    g = golden_more
+    T, m = U.extra_refine(g["few_mask"], g["few_X"], g["few_l1"], U.M2, g["few_r1"], U.K, acc=2)
+    assert T is None and not any(m) and len(m) == len(g["few_mask"])
