@@ -139,3 +139,83 @@ def test_the_package_never_touches_the_oracle_or_the_reference_tree():
                 if re.search(r"\b(import|from)\s+(slam_oracle|c_oracle)\b|[\"']oracle[\"'/]|open\([^)]*/root/reference", code):
                     bad.append(f"{f}:{line_no}: {line.strip()}")
     assert not bad, bad
+
+
+def _reference_loop(n, status, cnt, prob=0.9999, max_iterations=1e3):
+    """utils/utills.py:488-523 literally, over precomputed (solved?, supporters) per draw: returns
+    (iterations, draws consumed, best draw, ran out of draws)."""
+    outliers_perc, it, d, inl, outl, best, max_supp = 0.99, 0, 0, 0, 0, -1, -1
+
+    def est(o):
+        with np.errstate(divide="ignore"):
+            return np.log(1 - prob) / np.log(1 - np.power(1 - o, 4))
+
+    while outliers_perc != 0 and it < est(outliers_perc) and it < max_iterations:
+        if d >= len(status):
+            return it, d, best, True
+        k, d = d, d + 1
+        if not status[k]:
+            continue                                  # :506-507
+        num = int(cnt[k])
+        if num > max_supp:
+            max_supp, best = num, k
+        it += 1
+        outl += n - num
+        inl += num
+        outliers_perc = min(outl / (inl + outl), 0.99)
+    return it, d, best, False
+
+
+@pytest.mark.parametrize("case", ["clean", "half_outliers", "all_fail_then_good", "perfect", "hopeless"])
+def test_ransac_replay_follows_the_reference_loop(case):
+    """slam_ransac_replay (host only): the loop's bookkeeping over batches of precomputed hypotheses equals the
+    reference's loop draw for draw, whatever the batch boundaries; also what slam_track_pairs replays internally."""
+    import ctypes
+    rng = np.random.default_rng({"clean": 1, "half_outliers": 2, "all_fail_then_good": 3, "perfect": 4, "hopeless": 5}[case])
+    n, D = 900, 3000
+    status = (rng.random(D) > 0.1).astype(np.uint8)
+    if case == "clean":
+        cnt = rng.integers(700, 880, D)
+    elif case == "half_outliers":
+        cnt = np.where(rng.random(D) < 0.3, rng.integers(400, 500, D), rng.integers(0, 30, D))
+    elif case == "all_fail_then_good":
+        status[:200] = 0
+        cnt = rng.integers(600, 900, D)
+    elif case == "perfect":
+        cnt = np.full(D, n)                            # outliers_perc becomes 0: the loop stops after one iteration
+    else:
+        cnt = rng.integers(0, 5, D)                    # runs to the 1000-iteration cap
+    cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+    want = _reference_loop(n, status, cnt)
+    assert not want[3]
+    L = _lib.lib()
+    for batch in (64, 1, 257, D):
+        st = _lib.SlamRansacState()
+        assert L.slam_ransac_state_init(ctypes.byref(st)) == 0
+        begin = 0
+        while not st.finished:
+            end = min(begin + batch, D)
+            rc = L.slam_ransac_replay(ctypes.byref(st), n, status[begin:end].ctypes.data, cnt[begin:end].ctypes.data, begin, end,
+                                      0.9999, 1e3, 0, 0)
+            assert rc == 0 and st.draws <= end
+            begin = end
+        assert (st.it, st.draws, st.best_draw, st.hit_cap) == (want[0], want[1], want[2], 0), (case, batch)
+    # the bound on draws the reference does not have, and a batch that does not start where the loop stands
+    st = _lib.SlamRansacState()
+    L.slam_ransac_state_init(ctypes.byref(st))
+    zeros = np.zeros(50, np.uint8)
+    assert L.slam_ransac_replay(ctypes.byref(st), n, zeros.ctypes.data, cnt.ctypes.data, 0, 50, 0.9999, 1e3, 0, 40) == 0
+    assert st.finished and st.hit_cap and st.draws == 40 and st.best_draw == -1
+    st = _lib.SlamRansacState()
+    L.slam_ransac_state_init(ctypes.byref(st))
+    assert L.slam_ransac_replay(ctypes.byref(st), n, zeros.ctypes.data, cnt.ctypes.data, 10, 50, 0.9999, 1e3, 0, 0) == _lib.SLAM_E_INVALID
+
+
+def test_shutdown_is_idempotent_and_leaves_the_library_usable():
+    """slam_shutdown(): joins the host pool (nothing else to release without a GPU); host entry points still work."""
+    L = _lib.lib()
+    assert L.slam_shutdown() == 0 and L.slam_shutdown() == 0
+    out = np.empty(8, np.uint32)
+    assert L.slam_mt19937_words(5, out.ctypes.data, 8) == 0
+    np.random.seed(5)
+    assert np.array_equal(out, np.random.randint(0, 2 ** 32, 8, dtype=np.uint64).astype(np.uint32))

@@ -110,3 +110,41 @@ def test_small_reference_helpers(tmp_path):
     random.seed(1)
     assert U.get_rand_track(3, tr).get_id() == 1
     assert abs(U.mahalanobis_dist(np.array([3.0, 4.0]), np.diag([9.0, 16.0])) - np.sqrt(2.0)) < 1e-15
+
+
+def test_lazy_object_arrays_are_real_object_arrays_made_on_demand():
+    """KeyPointArray / DMatchArray / FeatureArray (what read_and_rec_match and find_features_in_consecutive_frames hand
+    out): numpy object arrays to every caller -- isinstance, dtype, len, int / slice / mask / index-array access,
+    iteration, sorted(), tolist(), copy(), pickle, numpy functions -- with the elements built when first read."""
+    import pickle
+    q, t, d = np.array([0, 2, 5, 9]), np.array([1, 3, 4, 7]), np.array([10, 20, 30, 5])
+    m = types.DMatchArray(q, t, d)
+    assert isinstance(m, np.ndarray) and m.dtype == object and m.shape == (4,) and len(m) == 4
+    assert int(m._filled.sum()) == 0                                     # nothing built yet
+    assert (m[1].queryIdx, m[1].trainIdx, m[1].distance) == (2, 3, 20.0) and isinstance(m[1].distance, float)
+    assert m[-1].queryIdx == 9 and int(m._filled.sum()) == 2
+    assert m[1] is m[1]                                                  # built once
+    with pytest.raises(IndexError):
+        m[4]
+    sub = m[[3, 0]]                                                      # the fancy index of utills.py:960
+    assert isinstance(sub, types.DMatchArray) and [x.queryIdx for x in sub] == [9, 0]
+    assert [x.trainIdx for x in m[np.array([True, False, True, False])]] == [1, 4]
+    assert [x.queryIdx for x in m[1:3]] == [2, 5] and len(m[:0]) == 0
+    assert [x.distance for x in sorted(m, key=lambda x: x.distance)] == [5.0, 10.0, 20.0, 30.0]     # bf_matching(sort=True)
+    assert np.array(m.materialise()).shape == (4,) and np.array(list(m), dtype=object).shape == (4,)
+    assert [x.queryIdx for x in m.tolist()] == [0, 2, 5, 9] and m.copy()[2].queryIdx == 5
+    assert [x.queryIdx for x in pickle.loads(pickle.dumps(m))] == [0, 2, 5, 9]
+    assert np.concatenate([m, m]).shape == (8,) and np.concatenate([m, m])[5].queryIdx == 2
+    raw = np.array(types.DMatchArray(q, t, d))                               # a raw copy made behind the array's back ...
+    with pytest.raises(RuntimeError):
+        raw[0].queryIdx                                                  # ... fails loudly instead of handing out junk
+    k = types.KeyPointArray(np.array([[1.5, 2.25], [3.1, 4.2]], np.float32))
+    assert k[0].pt == (1.5, 2.25) and k[1].pt == (float(np.float32(3.1)), float(np.float32(4.2)))
+    assert isinstance(k[1].pt[0], float)
+    f = types.FeatureArray([[1, 2], [3, 4]], np.array([[10, 11, 12, 13], [20, 21, 22, 23]], np.float32))
+    assert f[1].get_left_kpt() == 3 and f[1].get_right_kpt() == 4
+    assert f[1].get_left_coor() == (20.0, 21.0) and f[1].get_right_coor() == (22.0, 23.0)
+    sel = f[np.array([False, True])]
+    assert isinstance(sel, types.FeatureArray) and sel[0].__getstate__() == f[1].__getstate__()
+    f[0] = "x"                                                           # assignment works like on any object array
+    assert f[0] == "x" and f[1].get_left_kpt() == 3
