@@ -24,10 +24,42 @@
 
 namespace {
 
+// Sum over the 64 lanes, every lane ending with the same bits: a butterfly from stride 1 up to 32, with the partner's
+// value fetched by DPP inside a row of 16 lanes and by the gfx950 row / half swaps across rows -- VALU moves, no LDS.
+// (__shfl_xor compiles to two ds_bpermute_b32 per double and step; a pair's solve makes ~35 reductions of up to 27
+// values, and with 12 wavefronts per CU doing that at once the LDS crossbar, not the FP64 pipe, set the pace:
+// refit_kernel 0.468 -> see DESIGN section 4.)  At every step the lanes of a group already agree and two groups
+// exchange their values, so both end with the same (commutative) sum whichever lane of the other group is read: quad
+// swap, half-row mirror and row mirror serve as strides 4 and 8.  The tree differs from round 2's (which ran from
+// stride 32 down), so poses differ from that build's in the last digits (~1e-11 relative), not between launches.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)u, CTRL, 0xF, 0xF, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(u >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;   // xor butterfly: every lane ends with the same bits
+    v += dpp_f64<0xB1>(v);       // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_f64<0x4E>(v);       // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_f64<0x141>(v);      // row_half_mirror: the other quad of the 8
+    v += dpp_f64<0x140>(v);      // row_mirror: the other half of the row
+    {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);          // rows 0<->1, 2<->3
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+        v = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])) +
+            __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+    }
+    {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)u, (unsigned)u, false, false);          // lanes 0-31 <-> 32-63
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+        v = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])) +
+            __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+    }
+    return v;
 }
 
 // Cholesky solve of the 6x6 SPD system A x = b (upper triangle of A given, row-major full storage)
