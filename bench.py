@@ -80,6 +80,10 @@ def parse(argv=None):
                          "different streams start together; -1 (default): the tracker's own choice for the shard size")
     ap.add_argument("--no-ingest", action="store_true", help="skip the PCIe-inclusive leg (reported beside, never as, value)")
     ap.add_argument("--no-dropin", action="store_true", help="skip timing the reference-shaped whole-movie call")
+    ap.add_argument("--loops-plan", choices=("auto", "one", "two"), default="auto",
+                    help="--config loops with N > 1: one = a rank stereo-matches every frame its pair block touches, no "
+                         "data-path collective; two = every frame stereo-matched on one rank, keys all-gathered, then the "
+                         "pair blocks; auto = slam_amd.dist.pair_list_plan")
     ap.add_argument("--match-rule", choices=("ocv_legacy", "mutual", "knn"), default="ocv_legacy",
                     help="cross-check rule of the matcher (DESIGN.md section 2), or knn = the reference's REGULAR KNN "
                          "method (two nearest + ratio 0.6, utills.py:112-119); the headline uses the default")
@@ -712,9 +716,12 @@ def run_stress(args, rk: Rank):
 def run_loops(args, rk: Rank):
     """BASELINE configs[4]: loop-closure candidate validation, 3450 frames x 5 candidates each.  N = 1: one device pass.
     N > 1 (north_star: "Loop-closure candidate consensus matching ... shards the same way"): the ONE flat list of
-    (candidate, current) pairs block-partitioned over the ranks (slam_amd.dist.shard_list); a rank holds, stereo-matches
-    and tracks only the frames its block touches, no data-path collective, one all-gather of the 128-byte pose +
-    counter rows (strong scaling: `value` = all pairs / max-over-ranks time)."""
+    (candidate, current) pairs block-partitioned over the ranks (slam_amd.dist.shard_list), strong scaling: `value` = all
+    pairs / max-over-ranks time.  Two plans (slam_amd.dist.track_pairs_sharded): "one" -- a rank holds, stereo-matches and
+    tracks the frames its block touches, no data-path collective; "two" -- every frame is stereo-matched on ONE rank
+    (block partition of the frames), the keys are all-gathered (28 MB: the path's one exchange step, RCCL over xGMI) and
+    the pair blocks run on them, temporal problems only.  Either way one all-gather of the 128-byte pose + counter rows
+    ends the step."""
     torch = rk.torch
     from slam_amd import dist as sdist
     from slam_amd import pipeline
@@ -724,8 +731,16 @@ def run_loops(args, rk: Rank):
     n_max = scfg.n_max
     g0, g1 = loop_candidate_pairs(F)                                        # movie frame indices
     P_total = len(g0)
+    two_auto, cost_one, cost_two = sdist.pair_list_plan(g0, g1, F, rk.world)
+    two = rk.world > 1 and (args.loops_plan == "two" or (args.loops_plan == "auto" and two_auto))
     a, b = sdist.shard_list(P_total, rk.rank, rk.world)
     used, f0, f1 = sdist.frames_of_block(g0, g1, a, b)
+    fa, fb = sdist.block_range(F, rk.rank, rk.world)
+    if two:
+        # the rank holds its frame block (phase 1) and the frames its pair block touches (phase 2) as ONE ascending list;
+        # the frame block is a contiguous run of it
+        used = np.union1d(used, np.arange(fa, fb))
+        f0, f1 = np.searchsorted(used, g0[a:b]).astype(np.int32), np.searchsorted(used, g1[a:b]).astype(np.int32)
     seq = SynthSequence(scfg)
     t0 = time.time()
     Fl = len(used)
@@ -741,13 +756,28 @@ def run_loops(args, rk: Rank):
     gen_s = time.time() - t0
     P = b - a
     Fd = len(count)
-    trk = pipeline.ShardTracker(Fd, max(P, 1), n_max, hot_path_config(args), n_chunks=1)
+    hp = hot_path_config(args)
+    trk = pipeline.ShardTracker(Fd, max(P, 1), n_max, hp, n_chunks=1)
     dev_args = (torch.from_numpy(desc.reshape(2 * Fd, n_max, 64)).cuda(), torch.from_numpy(xy.reshape(2 * Fd, n_max, 2)).cuda(),
                 torch.from_numpy(count.reshape(2 * Fd)).cuda())
     seeds = 9000 + a + np.arange(P)                                         # a pair's seed is its index in the whole list
+    i0 = int(np.searchsorted(used, fa)) if two else 0                       # the frame block's place in the rank's list
+    used_dev = torch.from_numpy(np.asarray(used, np.int64)).cuda()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    phase_ms = []
 
     def step():
-        res = trk.run(*dev_args, f0, f1, seeds, unpack_mask=False)
+        keys = None
+        if two:
+            ev[0].record()
+            table = sdist.stereo_keys_sharded(
+                F, lambda x, y: pipeline.stereo_keys(dev_args[0][2 * i0:2 * (i0 + y - x)], dev_args[2][2 * i0:2 * (i0 + y - x)], hp))
+            ev[1].record()
+            keys = table.to(used_dev.device)[used_dev].contiguous()
+            ev[2].record()
+        res = trk.run(*dev_args, f0, f1, seeds, unpack_mask=False, stereo_key=keys)
+        if two:
+            phase_ms.append((ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])))
         pose, stats = sdist.gather_shard_results(res.pose, res.stats, P_total)
         return res, stats
 
@@ -767,12 +797,21 @@ def run_loops(args, rk: Rank):
     perc = 100.0 * stats[:, 1] / T
     near = np.arange(P_total) % 5 < 2
     cnt = count.astype(np.int64)
-    desc_pairs = int((cnt[:Fl, 0] * cnt[:Fl, 1]).sum() + (cnt[f0, 0] * cnt[f1, 0]).sum())
+    n_stereo = (fb - fa) if two else Fl                                     # stereo problems of rank 0 per step
+    s_lo = i0 if two else 0
+    desc_pairs = int((cnt[s_lo:s_lo + n_stereo, 0] * cnt[s_lo:s_lo + n_stereo, 1]).sum() + (cnt[f0, 0] * cnt[f1, 0]).sum())
     st = stage_dict(tm)
-    exec_rate = desc_pairs * EXEC_OPS_PER_PAIR / (st["match"] * 1e-3) / 1e12
+    if two:                                                                 # phase 1 is a matcher launch of its own
+        ph = np.array(phase_ms[-args.steps:])
+        st["stereo_phase_match_and_allgather"] = round(float(ph[:, 0].mean()), 3)
+        st["stereo_phase_gather_rows"] = round(float(ph[:, 1].mean()), 3)
+    exec_rate = desc_pairs * EXEC_OPS_PER_PAIR / ((st["match"] + (st["stereo_phase_match_and_allgather"] if two else 0)) * 1e-3) / 1e12
     world = rk.world
-    where = "one device pass" if world == 1 else (f"the ONE pair list block-partitioned over {world} GPUs, each rank holding only the "
-                                                  f"frames its block touches (at most {int(frames_per_rank)} of {F})")
+    where = "one device pass" if world == 1 else (
+        f"the ONE pair list block-partitioned over {world} GPUs, " +
+        (f"two phases: every frame stereo-matched on one rank ({fb - fa} per rank), keys all-gathered, then the pair blocks "
+         f"(temporal problems only; a rank holds at most {int(frames_per_rank)} of {F} frames)" if two else
+         f"one phase: each rank holding and stereo-matching the frames its block touches (at most {int(frames_per_rank)} of {F})"))
     out = {"metric": "frame-pairs/sec (match+triangulate+PnP-RANSAC)", "value": round(P_total * args.steps / elapsed, 2),
            "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
@@ -791,7 +830,9 @@ def run_loops(args, rk: Rank):
                        "mean_iterations": round(float(stats[:, 2].mean()), 1), "pairs": P_total},
            "setup_s": {"synthetic_generation": round(gen_s, 2)}}
     if world > 1:
-        out["roofline"]["note"] = "rank 0's launches (its block of the pair list)"
+        out["roofline"]["note"] = "rank 0's launches (its block of the pair list" + ("; phase 1's time includes the all-gather)" if two else ")")
+        out["config"]["plan"] = {"chosen": "two" if two else "one", "asked": args.loops_plan,
+                                 "matching_problems_of_the_busiest_rank": {"one_phase": int(cost_one), "two_phase": int(cost_two)}}
     rk.emit(out)
 
 

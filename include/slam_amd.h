@@ -325,6 +325,13 @@ typedef struct SlamTrackIO {
     /* scratch */
     void *d_workspace; size_t d_workspace_bytes;
     void *h_workspace; size_t h_workspace_bytes; /* pinned host memory */
+    /* optional device input (NULL = the call matches every frame's stereo pair itself): [n_frames][n_max] stereo keys of
+       the frames, i.e. d_key1 of slam_match_hamming_batched with problem f = (query image 2f, train image 2f+1) under the
+       same norm / match_mode / ratio.  The call then launches only the temporal problems and reads no right-image
+       descriptor.  For callers that have the stereo matches already: the reference computes a frame's stereo match once
+       per use (utils/utills.py:1126-1134 re-matches every candidate of every current frame); a multi-GPU loop-closure
+       pass matches each frame once on ONE rank and all-gathers the keys (slam_amd/dist.py). */
+    const uint32_t *d_stereo_key;
 } SlamTrackIO;
 
 /* status bits in h_stats[p][5] */

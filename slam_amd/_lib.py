@@ -44,7 +44,8 @@ class SlamTrackIO(ctypes.Structure):
                 ("d_tracked_kp", c_void_p),
                 ("h_pose", c_void_p), ("h_stats", c_void_p), ("h_mask", c_void_p),
                 ("d_workspace", c_void_p), ("d_workspace_bytes", c_size_t),
-                ("h_workspace", c_void_p), ("h_workspace_bytes", c_size_t)]
+                ("h_workspace", c_void_p), ("h_workspace_bytes", c_size_t),
+                ("d_stereo_key", c_void_p)]
 
 
 class SlamRansacState(ctypes.Structure):

@@ -309,6 +309,7 @@ struct Lane {
     const uint8_t *d_desc = nullptr;
     const float *d_xy = nullptr;
     const int32_t *d_count = nullptr;
+    const uint32_t *stereo_in = nullptr;             // the chunk's frames' stereo keys brought by the caller, or null
     std::vector<int32_t> f0, f1, order_start, order_fill;
     const uint32_t *seed = nullptr;
     std::vector<RansacReplay> rs;
@@ -336,6 +337,7 @@ struct Lane {
         d_desc = io->d_desc + (size_t)2 * lo * sh.N * 64;
         d_xy = io->d_xy + (size_t)2 * lo * sh.N * 2;
         d_count = io->d_count + 2 * lo;
+        stereo_in = io->d_stereo_key ? io->d_stereo_key + (size_t)lo * sh.N : nullptr;
         f0.resize(P);
         f1.resize(P);
         for (int p = 0; p < P; ++p) {
@@ -372,15 +374,20 @@ struct Lane {
             // whose later frame it is.  A left image is an operand of up to three problems (stereo f, temporal f-1 -> f
             // and f -> f+1); next to each other they run on one XCD at about the same time and the image comes from HBM
             // once instead of three times.  Counting sort, O(F + P).
+            // With the frames' stereo keys brought by the caller (SlamTrackIO::d_stereo_key) only the temporal problems
+            // are launched: the order then lists them alone, numbered from 0 (the problem arrays are passed from F on).
             int32_t *h_order = b.h_prob + (b.order - b.setup);
+            const int own = stereo_in ? 0 : 1;                                             // stereo problems of this call per frame
             order_start.assign(F + 1, 0);
             for (int p = 0; p < P; ++p) ++order_start[std::max(f0[p], f1[p]) + 1];
-            for (int f = 0; f < F; ++f) order_start[f + 1] += order_start[f] + 1;          // + the frame's stereo problem
-            for (int f = 0; f < F; ++f) h_order[order_start[f]] = f;
+            for (int f = 0; f < F; ++f) order_start[f + 1] += order_start[f] + own;        // + the frame's stereo problem
+            if (own)
+                for (int f = 0; f < F; ++f) h_order[order_start[f]] = f;
             order_fill.assign(order_start.begin(), order_start.end() - 1);
             for (int p = 0; p < P; ++p) {
                 const int f = std::max(f0[p], f1[p]);
-                h_order[++order_fill[f]] = F + p;
+                if (own) h_order[++order_fill[f]] = F + p;
+                else h_order[order_fill[f]++] = p;
             }
             SLAM_HIP_CHECK(hipMemcpyAsync(b.setup, b.h_prob, sizeof(int32_t) * b.setup_len, hipMemcpyHostToDevice, st));
             SLAM_HIP_CHECK(hipMemsetAsync(b.gate, 0, 4 * sizeof(int32_t), st));
@@ -388,13 +395,18 @@ struct Lane {
         if (match_after) SLAM_HIP_CHECK(hipStreamWaitEvent(st, match_after, 0));    // serial matchers: the previous chunk's has finished
         SLAM_HIP_CHECK(hipEventRecord(ev[0], st));
         // ---- 1. matching: F stereo + P temporal problems, ONE launch over the contiguous key array ----
-        rc = slam_launch_match_batched(d_desc, d_count, N, b.prob_q, b.prob_t, b.order, F + P, sh.norm, sh.match_mode,
-                                       sh.ratio, b.stereo_key, b.key2, b.match_ws, b.match_ws_bytes, st);
+        //         (P temporal problems alone when the caller brought the stereo keys)
+        {
+            const size_t skip = stereo_in ? (size_t)F : 0;                                 // problems not launched
+            rc = slam_launch_match_batched(d_desc, d_count, N, b.prob_q + skip, b.prob_t + skip, b.order, F + P - (int)skip, sh.norm,
+                                           sh.match_mode, sh.ratio, b.stereo_key + skip * N, b.key2 ? b.key2 + skip * N : nullptr,
+                                           b.match_ws, b.match_ws_bytes, st);
+        }
         if (rc) return rc;
         SLAM_HIP_CHECK(hipEventRecord(ev[1], st));
         SLAM_HIP_CHECK(hipEventRecord(ev_matched, st));
         // ---- 2. join, 3. triangulate ----
-        rc = slam_launch_rect_join(d_xy, d_count, N, b.stereo_key, b.temporal_key_at(F, N), b.pair_f0, b.pair_f1, P,
+        rc = slam_launch_rect_join(d_xy, d_count, N, stereo_in ? stereo_in : b.stereo_key, b.temporal_key_at(F, N), b.pair_f0, b.pair_f1, P,
                                    sh.cfg->rec_err, b.tcount, sh.io->d_tracked_kp + (size_t)pair0 * N * 4, b.xy0, b.xy1,
                                    b.aux, st);
         if (rc) return rc;

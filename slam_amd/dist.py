@@ -157,28 +157,88 @@ def frames_of_block(pair_f0: np.ndarray, pair_f1: np.ndarray, a: int, b: int):
     return used, np.searchsorted(used, f0).astype(np.int32), np.searchsorted(used, f1).astype(np.int32)
 
 
-def track_pairs_sharded(pair_f0, pair_f1, seeds, run_block, row_width: int, device=None):
+def pair_list_plan(pair_f0, pair_f1, n_frames: int, world: int):
+    """How a flat pair list over `n_frames` frames is best split over `world` ranks, in matching problems of the busiest
+    rank: one phase (`track_pairs_sharded` without exchange: a rank stereo-matches every frame its block touches, so a
+    frame is matched by every rank that needs it) against two phases (every frame stereo-matched on ONE rank, the keys
+    all-gathered, then the pair blocks).  -> (two_phase: bool, problems one-phase, problems two-phase).  A pure function
+    of the list, so every rank takes the same decision without talking."""
+    pair_f0, pair_f1 = np.asarray(pair_f0), np.asarray(pair_f1)
+    P = len(pair_f0)
+    one = two = 0
+    for r in range(world):
+        a, b = shard_list(P, r, world)
+        fa, fb = block_range(n_frames, r, world)
+        used = len(np.unique(np.concatenate([pair_f0[a:b], pair_f1[a:b]]))) if b > a else 0
+        one = max(one, used + (b - a))
+        two = max(two, (fb - fa) + (b - a))
+    return two < 0.9 * one, one, two
+
+
+def stereo_keys_sharded(n_frames: int, match_block, device=None) -> torch.Tensor:
+    """Phase 1 of the two-phase pair-list split -- the one real exchange step of this path (RCCL all-gather over xGMI
+    under the nccl backend).  The caller's frame list is block-partitioned (`block_range`); rank r stereo-matches its
+    frames, `match_block(frame_start, frame_stop) -> int32[frames, n_max]` packed keys (slam_amd.pipeline.stereo_keys),
+    and ONE all-gather leaves int32[n_frames, n_max] on every rank (on the collective's device: the GPU under nccl),
+    n_max being the widest block's (narrower blocks are padded with SLAM_KEY_NONE, which is what rows past an image's
+    count hold anyway).  28 MB for 3450 frames x 2048 rows."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    fa, fb = block_range(n_frames, rank, world)
+    dev = _coll_device(device) if dist.is_initialized() else None
+    local = match_block(fa, fb) if fb > fa else torch.empty((0, 64), dtype=torch.int32)
+    if local.dtype != torch.int32 or local.dim() != 2 or local.shape[0] != fb - fa:
+        raise ValueError("match_block must return int32[frames of the block, n_max]")
+    if not dist.is_initialized():
+        return local
+    n_max = max_over_ranks(local.shape[1], device=device)
+    local = local.to(dev)
+    if local.shape[1] != n_max:
+        wide = torch.full((local.shape[0], n_max), -1, dtype=torch.int32, device=dev)      # SLAM_KEY_NONE
+        wide[:, :local.shape[1]] = local
+        local = wide
+    return all_gather_rows(local, n_frames, world, rank)
+
+
+def track_pairs_sharded(pair_f0, pair_f1, seeds, run_block, row_width: int, device=None, n_frames: int | None = None,
+                        stereo_block=None, plan: str = "auto"):
     """A flat list of independent frame pairs -- the (candidate, current) pairs of loop-closure validation,
     PoseGraph.py:463-472 -> :386-410 -> utils/utills.py:1118-1146 -- block-partitioned over the ranks (`shard_list`).
 
     Rank r tracks only its block and the frames it touches:
-    `run_block(used_frames, f0_local, f1_local, seeds_block) -> (pose[p,3,4], stats[p,8], rows int32[m,row_width],
-    rows_per_pair int[p])`, with pair_f0 / pair_f1 the positions in the caller's frame list and `used_frames` the
-    ascending positions the block needs.  `seeds` (one per pair) are rank 0's: every other rank's argument is ignored,
-    so the result is what one process returns for rank 0's random stream.  No data-path collective; afterwards one
-    all-gather of the 128-byte pose + counter rows and one (ragged) of the supporters' rows leave
-    (pose [P,3,4], stats [P,8], rows [M,row_width], row pointer int64[P+1]) on every rank."""
+    `run_block(used_frames, f0_local, f1_local, seeds_block, stereo_key) -> (pose[p,3,4], stats[p,8], rows
+    int32[m,row_width], rows_per_pair int[p])`, with pair_f0 / pair_f1 the positions in the caller's frame list,
+    `used_frames` the ascending positions the block needs and `stereo_key` None (one phase: the block matches its frames'
+    stereo pairs itself) or those frames' rows of the all-gathered key table (two phases).  `seeds` (one per pair) are
+    rank 0's: every other rank's argument is ignored, so the result is what one process returns for rank 0's random
+    stream.
+
+    plan: "one" = no data-path collective (a frame is stereo-matched by every rank whose block touches it); "two" =
+    `stereo_keys_sharded(n_frames, stereo_block)` first, so every frame is matched once in the whole job, at the price of
+    one all-gather; "auto" = `pair_list_plan` (two phases when they take a tenth or more off the busiest rank's matching
+    problems -- candidates spread over the whole past; one when the blocks' frames hardly overlap).  Two phases need
+    `n_frames` and `stereo_block`.  Afterwards one all-gather of the 128-byte pose + counter rows and one (ragged) of the
+    supporters' rows leave (pose [P,3,4], stats [P,8], rows [M,row_width], row pointer int64[P+1]) on every rank."""
     pair_f0, pair_f1 = np.asarray(pair_f0, np.int32), np.asarray(pair_f1, np.int32)
     P = len(pair_f0)
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
+    if plan not in ("auto", "one", "two"):
+        raise ValueError("plan must be 'auto', 'one' or 'two'")
+    two = plan == "two"
+    if plan == "auto" and stereo_block is not None and n_frames is not None and world > 1:
+        two = pair_list_plan(pair_f0, pair_f1, n_frames, world)[0]
+    if two and (stereo_block is None or n_frames is None):
+        raise ValueError("the two-phase plan needs n_frames and stereo_block")
     seeds = broadcast_array(seeds if rank == 0 else None, (P,), np.int64, device=device).astype(np.uint64)
+    keys = stereo_keys_sharded(n_frames, stereo_block, device=device) if two else None
     a, b = shard_list(P, rank, world)
     pose_l, stats_l = np.zeros((0, 3, 4)), np.zeros((0, 8), np.int32)
     rows_l, cnt_l = np.zeros((0, row_width), np.int32), np.zeros(0, np.int64)
     if b > a:
         used, l0, l1 = frames_of_block(pair_f0, pair_f1, a, b)
-        pose_l, stats_l, rows_l, cnt_l = run_block(used, l0, l1, seeds[a:b])
+        sk = keys[torch.from_numpy(used).to(keys.device)] if keys is not None else None
+        pose_l, stats_l, rows_l, cnt_l = run_block(used, l0, l1, seeds[a:b], sk)
         if len(pose_l) != b - a or len(cnt_l) != b - a or rows_l.shape[1:] != (row_width,):
             raise ValueError("run_block returned arrays of the wrong shape for its block")
     pose, stats = gather_shard_results(pose_l, stats_l, P, device=device)

@@ -86,13 +86,19 @@ class ShardTracker:
         self.h_mask = torch.empty((n_pairs, n_max // 64), dtype=torch.int64).pin_memory()
 
     def run(self, desc: torch.Tensor, xy: torch.Tensor, count: torch.Tensor, pair_f0: np.ndarray, pair_f1: np.ndarray,
-            seeds: np.ndarray, unpack_mask: bool = True) -> ShardResult:
+            seeds: np.ndarray, unpack_mask: bool = True, stereo_key: torch.Tensor | None = None) -> ShardResult:
         """desc uint8[2F, n_max, 64], xy float32[2F, n_max, 2], count int32[2F] on the device (image 2f = left of
-        frame f, 2f+1 = right); pair_f0/f1 int32[P] frame indices; seeds uint32[P] (np.random.seed per pair)."""
+        frame f, 2f+1 = right); pair_f0/f1 int32[P] frame indices; seeds uint32[P] (np.random.seed per pair).
+        stereo_key (optional) int32[F, n_max] on the device: the frames' stereo keys computed earlier (`stereo_keys`,
+        possibly on another rank); the call then matches only the temporal problems and reads no right-image descriptor."""
         F = desc.shape[0] // 2
         P = len(pair_f0)
         if F > self.n_frames or P > self.n_pairs or desc.shape[1] != self.n_max:
             raise ValueError("shard larger than the tracker's workspace")
+        if stereo_key is not None:
+            if tuple(stereo_key.shape) != (F, self.n_max):
+                raise ValueError("stereo_key must hold one row of n_max keys per frame")
+            ops._dev(stereo_key, torch.int32)
         f0 = np.ascontiguousarray(pair_f0, dtype=np.int32)
         f1 = np.ascontiguousarray(pair_f1, dtype=np.int32)
         sd = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64) & 0xFFFFFFFF, dtype=np.uint32)
@@ -121,6 +127,7 @@ class ShardTracker:
             io.h_mask = self.h_mask.data_ptr() + a * (self.n_max // 64) * 8
             io.d_workspace, io.d_workspace_bytes = self.d_ws.data_ptr(), self.d_ws_bytes
             io.h_workspace, io.h_workspace_bytes = self.h_ws.data_ptr(), self.h_ws_bytes
+            io.d_stereo_key = stereo_key.data_ptr() + lo * self.n_max * 4 if stereo_key is not None else None
             _lib.check(L.slam_track_pairs(ctypes.byref(self._c), ctypes.byref(io), ops._stream()))
             t1 = np.zeros(8)
             L.slam_track_last_timing(t1.ctypes.data)
@@ -132,6 +139,21 @@ class ShardTracker:
         else:
             mask = self.h_mask[:P].numpy().copy()
         return ShardResult(pose=pose, stats=stats, mask=mask, tracked_kp=self.tracked_kp[:P], timing_ms=tm)
+
+
+def stereo_keys(desc: torch.Tensor, count: torch.Tensor, cfg: HotPathConfig | None = None) -> torch.Tensor:
+    """The stereo match of every frame on its own (read_and_rec_match's match() call, utils/utills.py:386-396), as the
+    packed keys slam_track_pairs computes for itself: desc uint8[2F, n_max, 64], count int32[2F] (image 2f = left of frame
+    f, 2f+1 = right) -> int32[F, n_max] on the device.  Feeding them back through ShardTracker.run(stereo_key=...) gives
+    the results of the call that matches them itself, bit for bit; a multi-GPU loop-closure pass uses it to match every
+    frame on ONE rank (slam_amd.dist.stereo_keys_sharded)."""
+    cfg = cfg or HotPathConfig()
+    F = desc.shape[0] // 2
+    q = torch.arange(0, 2 * F, 2, dtype=torch.int32, device=desc.device)
+    mode = cfg.match_mode()
+    ratio = (float(cfg.ratio) if cfg.ratio > 0 else 0.6) if mode == _lib.SLAM_MATCH_KNN2 else 0.0
+    key1, _ = ops.match_keys_batched(desc, count, q, q + 1, cfg.norm, mode, ratio)
+    return key1
 
 
 def consecutive_pairs(n_frames: int):

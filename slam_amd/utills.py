@@ -683,10 +683,24 @@ def _source_arrays(frames):
     return desc, xy, count
 
 
-def track_pairs_arrays(frames, pair_f0, pair_f1, seeds=None, host_kp=True):
+def _fit_keys(stereo_key, n_max):
+    """Stereo keys int32[F, w] (any device) at the width of this call's arrays: rows past an image's count hold
+    SLAM_KEY_NONE, so cutting or padding with it changes nothing."""
+    k = stereo_key.to(ops.device())
+    if k.shape[1] > n_max:
+        k = k[:, :n_max]
+    elif k.shape[1] < n_max:
+        wide = torch.full((k.shape[0], n_max), -1, dtype=torch.int32, device=k.device)
+        wide[:, :k.shape[1]] = k
+        k = wide
+    return k.contiguous()
+
+
+def track_pairs_arrays(frames, pair_f0, pair_f1, seeds=None, host_kp=True, stereo_key=None):
     """Batched core of the drivers below: frames = movie indices, pair_f0/f1 = positions in `frames`.
     Returns (ShardResult, xy float32[F,2,n_max,2], tracked key-point indices int32[P,n_max,4]); with host_kp=False the
-    result keeps the supporter masks as bit words and the indices stay on the device (ShardResult.tracked_kp)."""
+    result keeps the supporter masks as bit words and the indices stay on the device (ShardResult.tracked_kp).
+    stereo_key: the frames' stereo keys (`stereo_keys_of`) when they were matched earlier, possibly on another rank."""
     desc, xy, count = _source_arrays(frames)
     F, _, n_max, _ = desc.shape
     P = len(pair_f0)
@@ -694,8 +708,17 @@ def track_pairs_arrays(frames, pair_f0, pair_f1, seeds=None, host_kp=True):
         seeds = np.random.randint(0, 2 ** 32, P, dtype=np.uint64)      # one draw from the global stream per pair
     trk = pipeline.ShardTracker(F, P, n_max, _hot_path_config())
     res = trk.run(_cuda(desc.reshape(2 * F, n_max, 64)), _cuda(xy.reshape(2 * F, n_max, 2)), _cuda(count.reshape(2 * F)),
-                  np.asarray(pair_f0, np.int32), np.asarray(pair_f1, np.int32), seeds, unpack_mask=host_kp)
+                  np.asarray(pair_f0, np.int32), np.asarray(pair_f1, np.int32), seeds, unpack_mask=host_kp,
+                  stereo_key=_fit_keys(stereo_key, n_max) if stereo_key is not None else None)
     return res, xy, (res.tracked_kp.cpu().numpy() if host_kp else None)
+
+
+def stereo_keys_of(frames):
+    """The stereo match of each of `frames` (movie indices) as packed device keys int32[F, n_max]: what
+    read_and_rec_match's match() call (:386-396) produces, once per frame."""
+    desc, _, count = _source_arrays(frames)
+    F, _, n_max, _ = desc.shape
+    return pipeline.stereo_keys(_cuda(desc.reshape(2 * F, n_max, 64)), _cuda(count.reshape(2 * F)), _hot_path_config())
 
 
 def _features_of(kp_lr, xy_frame):
@@ -896,13 +919,13 @@ def apply_full_consensus_match(first_frame, second_frame):
     return trans, f0, f1, mask, perc
 
 
-def _pair_supporter_rows(frames, pair_f0, pair_f1, seeds):
+def _pair_supporter_rows(frames, pair_f0, pair_f1, seeds, stereo_key=None):
     """One device pass over a list of frame pairs, reduced to what loop-closure validation hands on (:1136-1143): per
     pair the counters, and per supporter ONE 12-word row -- key-point indices (L0, R0, L1, R1) and, as float32 bit
     patterns, the eight coordinates (xL0, yL0, xR0, yR0, xL1, yL1, xR1, yR1) its two Features are built from.
     -> (pose float64[P,3,4], stats int32[P,8], rows int32[M,12], rows per pair int64[P])."""
     pair_f0, pair_f1 = np.asarray(pair_f0, np.int32), np.asarray(pair_f1, np.int32)
-    res, xy, _ = track_pairs_arrays(frames, pair_f0, pair_f1, seeds, host_kp=False)
+    res, xy, _ = track_pairs_arrays(frames, pair_f0, pair_f1, seeds, host_kp=False, stereo_key=stereo_key)
     flat, ptr = ops.compact_supporters(res.mask, res.stats[:, 0], res.tracked_kp)
     cnt = np.diff(ptr)
     g0, g1 = np.repeat(pair_f0, cnt), np.repeat(pair_f1, cnt)
@@ -914,11 +937,16 @@ def _pair_supporter_rows(frames, pair_f0, pair_f1, seeds):
     return res.pose, res.stats, rows, cnt
 
 
+LOOP_SHARD_PLAN = "auto"      # slam_amd.dist.track_pairs_sharded's plan for the loop-closure doors: "auto", "one" or "two"
+
+
 def _loop_pair_rows(frames, pair_f0, pair_f1, seeds):
     """_pair_supporter_rows of the whole pair list: in one process, or -- when the caller has initialised
     torch.distributed with more than one rank -- block-partitioned over the ranks (slam_amd.dist.track_pairs_sharded:
-    each rank reads, stereo-matches and tracks only the frames its block touches; seeds are rank 0's; the results are
-    all-gathered, so every rank returns the whole list's arrays, equal to the one-process call's).
+    each rank reads and tracks only the frames its block touches; a frame's stereo match is computed by every rank that
+    needs it, or -- when the candidates are spread so widely that this repeats much of the work -- once in the whole
+    job, the keys all-gathered; seeds are rank 0's; the results are all-gathered, so every rank returns the whole list's
+    arrays, equal to the one-process call's).
     -> (stats int32[P,8], rows int32[M,12], row pointer int64[P+1])."""
     import torch.distributed as tdist
     frames = np.asarray(frames)
@@ -928,7 +956,8 @@ def _loop_pair_rows(frames, pair_f0, pair_f1, seeds):
         if seeds is None and tdist.get_rank() == 0:
             seeds = np.random.randint(0, 2 ** 32, P, dtype=np.uint64)      # one draw from the global stream per pair
         _, stats, rows, ptr = sdist.track_pairs_sharded(
-            pair_f0, pair_f1, seeds, lambda used, l0, l1, sd: _pair_supporter_rows(frames[used], l0, l1, sd), 12)
+            pair_f0, pair_f1, seeds, lambda used, l0, l1, sd, sk: _pair_supporter_rows(frames[used], l0, l1, sd, sk), 12,
+            n_frames=len(frames), stereo_block=lambda fa, fb: stereo_keys_of(frames[fa:fb]), plan=LOOP_SHARD_PLAN)
     else:
         _, stats, rows, cnt = _pair_supporter_rows(frames, pair_f0, pair_f1, seeds)
         ptr = np.zeros(P + 1, np.int64)

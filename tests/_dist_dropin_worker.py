@@ -50,6 +50,7 @@ def main():
     g = np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"), allow_pickle=False)
     U.set_detection_source(U.ArrayDetections(g["movie_desc"], g["movie_xy"], g["movie_count"]))
     if len(sys.argv) > 2 and sys.argv[2] == "loops":
+        U.LOOP_SHARD_PLAN = os.environ.get("SLAM_TEST_LOOP_PLAN", "auto")    # one phase, or stereo keys matched once + all-gathered
         loops(out_dir, rank)
         dist.barrier()
         dist.destroy_process_group()

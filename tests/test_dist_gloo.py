@@ -137,12 +137,17 @@ def _loop_case(n_pairs, n_frames=40):
 def _fake_block(frames):
     """Stand-in for the device pass: a pair's results are a function of its two MOVIE frames and its seed only, so a
     block that mis-translates frame positions or seeds shows up in the gathered arrays."""
-    def run(used, l0, l1, seeds):
+    def run(used, l0, l1, seeds, stereo_key=None):
         g0, g1 = frames[used][l0], frames[used][l1]
         p = len(l0)
         pose = np.array([_fake_pose(int(a) * 1000 + int(b)) for a, b in zip(g0, g1)]).reshape(p, 3, 4)
         stats = np.zeros((p, 8), np.int32)
         stats[:, 0], stats[:, 1], stats[:, 2], stats[:, 3] = g0, g1, (seeds & 0x7FFFFFFF).astype(np.int32), len(used)
+        if stereo_key is not None:                                                     # two phases: the used frames' key rows
+            sk = stereo_key.cpu().numpy()
+            assert sk.shape[0] == len(used)
+            stats[:, 4], stats[:, 5], stats[:, 6] = sk[l0, 0], sk[l1, 1], sk.shape[1]
+            stats[:, 7] = (sk[:, 64:] == -1).all()                                     # narrower blocks padded with KEY_NONE
         cnt = ((g0 + 2 * g1) % 4).astype(np.int64)                                     # some pairs without a row
         rows = np.array([[a, b, k] + [int(s) & 0xFFFF] * 9 for a, b, s, c in zip(g0, g1, seeds, cnt) for k in range(c)],
                         np.int32).reshape(-1, 12)
@@ -150,13 +155,24 @@ def _fake_block(frames):
     return run
 
 
-def _loop_worker(rank, world, port, n_pairs, q):
+def _fake_stereo(frames, rank):
+    """Stand-in for phase 1: a frame's key row is a function of its MOVIE index; every rank returns its own width."""
+    import torch
+
+    def match_block(fa, fb):
+        w = 64 * (rank + 1)
+        return (torch.from_numpy(frames[fa:fb].astype(np.int32))[:, None] * 1000 + torch.arange(w, dtype=torch.int32)[None]).contiguous()
+    return match_block
+
+
+def _loop_worker(rank, world, port, n_pairs, q, plan="one"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     f0, f1, seeds = _loop_case(n_pairs)
     frames = np.arange(100, 140)                                                        # movie indices behind the positions
     mine = seeds if rank == 0 else np.zeros_like(seeds)                                 # only rank 0's seeds may matter
-    q.put((rank,) + sdist.track_pairs_sharded(f0, f1, mine, _fake_block(frames), 12))
+    q.put((rank,) + sdist.track_pairs_sharded(f0, f1, mine, _fake_block(frames), 12, n_frames=len(frames),
+                                              stereo_block=_fake_stereo(frames, rank), plan=plan))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -189,3 +205,43 @@ def test_pair_list_shards_gather_to_the_single_process_result():
                     assert (stats[a:b, 3] == len(np.unique(np.concatenate([f0[a:b], f1[a:b]])))).all()
     used, l0, l1 = sdist.frames_of_block(np.array([5, 9, 5]), np.array([7, 5, 30]), 0, 3)
     assert used.tolist() == [5, 7, 9, 30] and l0.tolist() == [0, 2, 0] and l1.tolist() == [1, 0, 3]
+
+
+def test_pair_list_in_two_phases_hands_every_block_its_frames_stereo_keys():
+    """The two-phase plan of the pair-list split: every frame is stereo-matched on ONE rank (block partition
+    of the frame list), the keys are all-gathered -- the path's one exchange step -- and each pair block receives the key
+    rows of exactly the frames it touches, in their order.  Ranks return blocks of different widths (padded with
+    SLAM_KEY_NONE to the widest); worlds 2 and 3 and a world with a rank without pairs.  Everything else must equal the
+    one-phase result."""
+    frames = np.arange(100, 140)
+    for world, n_pairs in ((2, 11), (3, 10), (3, 2)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_loop_worker, args=(r, world, port, n_pairs, q, "two")) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        f0, f1, seeds = _loop_case(n_pairs)
+        w_pose, w_stats, w_rows, w_cnt = _fake_block(frames)(np.arange(40), f0, f1, seeds)
+        for rank, pose, stats, rows, ptr in got:
+            assert np.array_equal(pose, w_pose) and np.array_equal(stats[:, :3], w_stats[:, :3])
+            assert np.array_equal(rows, w_rows) and np.array_equal(ptr, np.concatenate([[0], np.cumsum(w_cnt)]))
+            assert np.array_equal(stats[:, 4], frames[f0] * 1000) and np.array_equal(stats[:, 5], frames[f1] * 1000 + 1)
+            assert (stats[:, 6] == 64 * world).all()
+
+
+def test_pair_list_plan_picks_two_phases_only_when_the_blocks_share_frames():
+    rng = np.random.default_rng(3)
+    F = 400
+    cur = np.repeat(np.arange(1, F), 5)
+    spread = np.array([rng.integers(0, c) for c in cur])                                # candidates anywhere in the past
+    two, one_cost, two_cost = sdist.pair_list_plan(spread, cur, F, 8)
+    assert two and two_cost < one_cost
+    f0 = np.arange(F - 1)                                                                # consecutive pairs: a halo frame per block
+    two, one_cost, two_cost = sdist.pair_list_plan(f0, f0 + 1, F, 8)
+    assert not two and one_cost == 50 + 51 and two_cost == 50 + 50
+    assert sdist.pair_list_plan(spread, cur, F, 1)[0] is False                          # one rank: nothing to share

@@ -279,6 +279,41 @@ def test_results_do_not_depend_on_chunk_plan():
         assert np.array_equal(res.tracked_kp.cpu().numpy(), base.tracked_kp.cpu().numpy()), (chunks, taper)
 
 
+@pytest.mark.parametrize("method,rule", [("bf", "ocv_legacy"), ("bf", "mutual"), ("knn", "ocv_legacy")])
+def test_stereo_keys_brought_by_the_caller_give_the_results_of_the_call_that_matches_them_itself(method, rule):
+    """SlamTrackIO::d_stereo_key (phase 2 of the multi-GPU loop-closure split, DESIGN 6): with the frames' stereo keys
+    computed beforehand (pipeline.stereo_keys = slam_match_hamming_batched on every (left, right) pair) the call launches
+    the temporal problems alone and must return what it returns when it matches the stereo pairs itself, bit for bit --
+    one lane and chunked, consecutive pairs and a loop-closure-shaped list; the right images' descriptors are then not
+    read at all (overwritten with noise here)."""
+    from slam_amd import pipeline
+    from slam_amd.config import BRUTE_FORCE, MUTUAL, OCV_LEGACY, REGULAR_KNN
+    hp = HotPathConfig(match_method=BRUTE_FORCE if method == "bf" else REGULAR_KNN,
+                       crosscheck_rule=MUTUAL if rule == "mutual" else OCV_LEGACY)
+    F = 40
+    cfg = SynthConfig(n_frames=F, n_features=500, seed=33, ragged=True)
+    desc, xy, count = SynthSequence(cfg).frames(0, F)
+    n_max = cfg.n_max
+    d_desc, d_xy, d_count = dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F))
+    keys = pipeline.stereo_keys(d_desc, d_count, hp)
+    assert keys.shape == (F, n_max) and keys.dtype == torch.int32
+    noisy = d_desc.clone()
+    noisy[1::2] = torch.randint(0, 256, noisy[1::2].shape, dtype=torch.uint8, device=noisy.device)
+    rng = np.random.default_rng(5)
+    lists = [consecutive_pairs(F),
+             (np.array([int(rng.integers(0, c)) for c in range(5, F) for _ in range(3)], np.int32), np.repeat(np.arange(5, F), 3).astype(np.int32))]
+    for f0, f1 in lists:
+        seeds = 400 + np.arange(len(f0))
+        for chunks in (1, 3):
+            base = ShardTracker(F, len(f0), n_max, hp, n_chunks=chunks).run(d_desc, d_xy, d_count, f0, f1, seeds)
+            res = ShardTracker(F, len(f0), n_max, hp, n_chunks=chunks).run(noisy, d_xy, d_count, f0, f1, seeds, stereo_key=keys)
+            assert np.array_equal(res.pose, base.pose, equal_nan=True) and np.array_equal(res.mask, base.mask)
+            assert np.array_equal(res.stats, base.stats) and (base.stats[:, 5] & _lib.SLAM_PAIR_OK).mean() > 0.3
+            assert np.array_equal(res.tracked_kp.cpu().numpy(), base.tracked_kp.cpu().numpy())
+    with pytest.raises(ValueError):
+        ShardTracker(F, F - 1, n_max, hp).run(d_desc, d_xy, d_count, *consecutive_pairs(F), seeds[:F - 1], stereo_key=keys[:-1])
+
+
 def test_a_pairs_pose_does_not_depend_on_the_size_of_its_launch():
     """The refit's summation order (wavefronts per pair, LDS or global walk) is a function of the pair's own layout,
     never of how many pairs share the launch: round 2 switched both on the launch size (768 / 256 pairs), so a pair's pose

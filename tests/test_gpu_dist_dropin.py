@@ -49,13 +49,15 @@ def test_sharded_whole_movie_equals_the_single_process_call(golden, tmp_path, wo
             assert int(z["stream_after"]) == after            # rank 0's global stream advanced exactly as one process's does
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_loop_closure_validation_equals_the_single_process_call(golden, tmp_path, world):
+@pytest.mark.parametrize("world,plan", [(2, "one"), (3, "one"), (2, "two"), (3, "two")])
+def test_sharded_loop_closure_validation_equals_the_single_process_call(golden, tmp_path, world, plan):
     """SURVEY 8(e), the second split north_star names: the flat (candidate, current) pair list of loop-closure
     validation (PoseGraph.py:463-472 -> utils/utills.py:1118-1146) block-partitioned over the ranks.  Every rank must
     return what one process returns for rank 0's random stream: which candidates pass, and every little track (ids,
     frame ids, key-point indices, coordinates); rank 0's global stream must advance as one process's does.  Six pairs
-    over 2 and 3 ranks (blocks of 3 and of 2); a current frame without candidates; one frame's candidates alone."""
+    over 2 and 3 ranks (blocks of 3 and of 2); a current frame without candidates; one frame's candidates alone.
+    plan "one": a rank stereo-matches every frame its block touches; plan "two": every frame is stereo-matched on one
+    rank, the keys are all-gathered (the path's one exchange step) and the pair blocks run on them."""
     import json
     sys.path.insert(0, HERE)
     import _dist_dropin_worker as W
@@ -74,7 +76,7 @@ def test_sharded_loop_closure_validation_equals_the_single_process_call(golden, 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, SLAM_TEST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    env = dict(os.environ, SLAM_TEST_BACKEND="gloo", OMP_NUM_THREADS="2", SLAM_TEST_LOOP_PLAN=plan)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(HERE, "_dist_dropin_worker.py"), str(tmp_path), "loops"]
     run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
