@@ -358,7 +358,7 @@ def run_trajectory(args, rk: Rank):
                     "mean_iterations": round(float(res.stats[:, 2].mean()), 2)},
         "setup_s": {"synthetic_generation": round(leg["gen_s"], 2)},
     }
-    if world > 1:
+    if world > 1 or two:
         out["roofline"]["note"] = "rank 0's launches (its block of the sequence)"
     if weak is not None:
         out["weak"] = weak
@@ -732,7 +732,10 @@ def run_loops(args, rk: Rank):
     g0, g1 = loop_candidate_pairs(F)                                        # movie frame indices
     P_total = len(g0)
     two_auto, cost_one, cost_two = sdist.pair_list_plan(g0, g1, F, rk.world)
-    two = rk.world > 1 and (args.loops_plan == "two" or (args.loops_plan == "auto" and two_auto))
+    # (a one-rank process group, SLAM_BENCH_FORCE_DIST=1, takes the two-phase path when asked: it rehearses the RCCL
+    # all-gather of the key table on a one-GPU box)
+    two = (rk.world > 1 and (args.loops_plan == "two" or (args.loops_plan == "auto" and two_auto))) or \
+          (rk.use_dist and args.loops_plan == "two")
     a, b = sdist.shard_list(P_total, rk.rank, rk.world)
     used, f0, f1 = sdist.frames_of_block(g0, g1, a, b)
     fa, fb = sdist.block_range(F, rk.rank, rk.world)
@@ -829,7 +832,7 @@ def run_loops(args, rk: Rank):
                        "others_over_85pct": round(float((perc[~near] > 85).mean()), 4),
                        "mean_iterations": round(float(stats[:, 2].mean()), 1), "pairs": P_total},
            "setup_s": {"synthetic_generation": round(gen_s, 2)}}
-    if world > 1:
+    if world > 1 or two:
         out["roofline"]["note"] = "rank 0's launches (its block of the pair list" + ("; phase 1's time includes the all-gather)" if two else ")")
         out["config"]["plan"] = {"chosen": "two" if two else "one", "asked": args.loops_plan,
                                  "matching_problems_of_the_busiest_rank": {"one_phase": int(cost_one), "two_phase": int(cost_two)}}
