@@ -358,7 +358,7 @@ def run_trajectory(args, rk: Rank):
                     "mean_iterations": round(float(res.stats[:, 2].mean()), 2)},
         "setup_s": {"synthetic_generation": round(leg["gen_s"], 2)},
     }
-    if world > 1 or two:
+    if world > 1:
         out["roofline"]["note"] = "rank 0's launches (its block of the sequence)"
     if weak is not None:
         out["weak"] = weak
