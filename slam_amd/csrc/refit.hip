@@ -138,11 +138,23 @@ __device__ __forceinline__ Pose apply_step(const Pose &P, const double (&d)[6]) 
 }
 
 constexpr int MAX_EVAL = 60;
-// Squared relative size of a step after which the solve stops.  The iteration converges quadratically (the damping
-// is down to 1e-3 x 0.1^k by step k), so the pose AFTER a step of relative size 1e-9 is already exact to rounding;
-// asking for a step below 1e-13 (1e-26 here) cost one more Jacobian + cost pass that changed nothing.
+// Stopping rule: the solve ends with the first trial step whose relative size is below FLT_EPSILON -- CvLevMarq's own
+// criterion for cv2.solvePnP(ITERATIVE) (the reference's refit, utils/utills.py:562-563) -- whether that step is accepted
+// (it is applied) or rejected (the pose stays).  SLAM_REFIT_STEP2 is the square of that relative size.  The iteration
+// converges quadratically on top of a damping that is down to 1e-3 x 0.1^k by step k, so the pose after an accepted
+// step of relative size s is within ~max(1e-5 s, s^2) of the minimiser: ~1e-12 here.
+// Measured on bench-shaped pairs (tools/refit_evals_hist.py, a probe build counting trial steps): rounds 1-3 stopped on
+// an ACCEPTED step below 1e-9 only and went on, after a rejected one, until the step was below 1e-15 relative -- at the
+// minimum the cost comparison is rounding noise, so half the pairs took 5 to 16 trial steps (mean 6.3) for a pose that
+// moved by < 1.2e-10; with this rule every pair takes 3 or 4 (mean 3.2), the poses differ from the fully converged ones
+// by 4e-12 (median) / 2e-9 (worst) relative -- the parity bar is 1e-5 -- and the refit of a whole shard takes 0.27
+// instead of 0.40 ms, that of a rank's share at N = 8 (432 pairs: the launch lasts as long as its slowest pair) 0.06
+// instead of 0.10 ms.
 #ifndef SLAM_REFIT_STEP2
-#define SLAM_REFIT_STEP2 1e-18
+#define SLAM_REFIT_STEP2 1.42e-14        /* FLT_EPSILON^2 */
+#endif
+#ifndef SLAM_REFIT_REJECT_STEP2
+#define SLAM_REFIT_REJECT_STEP2 SLAM_REFIT_STEP2
 #endif
 
 // Wavefronts per pair (RW).  A pair's solve is one long dependent chain (passes over the supporters, 27 butterfly
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(RW * 64) void refit_kernel(Mat33 K, const double *X
                 if (tiny) done = true;
             } else {
                 lambda *= 10.0;
-                if (lambda > 1e16 || dn <= 1e-30 * pn) done = true, stepped = true;
+                if (lambda > 1e16 || dn <= SLAM_REFIT_REJECT_STEP2 * pn) done = true, stepped = true;
             }
         }
     }
@@ -389,7 +401,11 @@ __global__ __launch_bounds__(RW * 64) void refit_kernel(Mat33 K, const double *X
             for (int j = 0; j < 3; ++j) pose_out[(size_t)seg * 12 + i * 4 + j] = P.R[i][j];
             pose_out[(size_t)seg * 12 + i * 4 + 3] = P.t[i];
         }
+#ifdef SLAM_REFIT_PROBE
+        status[seg] = (uint8_t)(evals > 0 ? evals : 1);
+#else
         status[seg] = 1;
+#endif
     }
 }
 
