@@ -44,8 +44,7 @@ class SlamTrackIO(ctypes.Structure):
                 ("d_tracked_kp", c_void_p),
                 ("h_pose", c_void_p), ("h_stats", c_void_p), ("h_mask", c_void_p),
                 ("d_workspace", c_void_p), ("d_workspace_bytes", c_size_t),
-                ("h_workspace", c_void_p), ("h_workspace_bytes", c_size_t),
-                ("d_stereo_key", c_void_p)]
+                ("h_workspace", c_void_p), ("h_workspace_bytes", c_size_t)]
 
 
 class SlamRansacState(ctypes.Structure):
@@ -92,6 +91,7 @@ SIGNATURES = {
     "slam_track_device_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_void_p]),
     "slam_track_host_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_void_p]),
     "slam_track_pairs": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "slam_track_pairs_stereo_keys": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "slam_track_last_timing": (c_int, [c_void_p]),
 }
 

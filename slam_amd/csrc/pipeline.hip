@@ -279,6 +279,7 @@ struct Shared {
     double thr, ratio;
     int norm, N, match_mode;
     bool outputs_pinned;             // h_pose / h_mask are page-locked: copies into them can be queued without blocking
+    const uint32_t *stereo_key;      // [n_frames][n_max] stereo keys brought by the caller (slam_track_pairs_stereo_keys), or null
 };
 
 // page-locked (hipHostMalloc / hipHostRegister) host memory?  A copy into pageable memory blocks the queueing thread
@@ -337,7 +338,7 @@ struct Lane {
         d_desc = io->d_desc + (size_t)2 * lo * sh.N * 64;
         d_xy = io->d_xy + (size_t)2 * lo * sh.N * 2;
         d_count = io->d_count + 2 * lo;
-        stereo_in = io->d_stereo_key ? io->d_stereo_key + (size_t)lo * sh.N : nullptr;
+        stereo_in = sh.stereo_key ? sh.stereo_key + (size_t)lo * sh.N : nullptr;
         f0.resize(P);
         f1.resize(P);
         for (int p = 0; p < P; ++p) {
@@ -374,7 +375,7 @@ struct Lane {
             // whose later frame it is.  A left image is an operand of up to three problems (stereo f, temporal f-1 -> f
             // and f -> f+1); next to each other they run on one XCD at about the same time and the image comes from HBM
             // once instead of three times.  Counting sort, O(F + P).
-            // With the frames' stereo keys brought by the caller (SlamTrackIO::d_stereo_key) only the temporal problems
+            // With the frames' stereo keys brought by the caller (slam_track_pairs_stereo_keys) only the temporal problems
             // are launched: the order then lists them alone, numbered from 0 (the problem arrays are passed from F on).
             int32_t *h_order = b.h_prob + (b.order - b.setup);
             const int own = stereo_in ? 0 : 1;                                             // stereo problems of this call per frame
@@ -833,7 +834,8 @@ extern "C" int slam_track_last_timing(double *h_ms8) {
     return SLAM_OK;
 }
 
-extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *io, void *stream) try {
+namespace {
+int track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *io, const uint32_t *d_stereo_key, void *stream) {
     const double t_begin = now_ms();
     hipStream_t st = (hipStream_t)stream;
     SLAM_REQUIRE(cfg && io, "slam_track_pairs: null config/io");
@@ -874,6 +876,7 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
     sh.match_mode = cfg->match_mode;
     sh.ratio = cfg->ratio > 0 ? cfg->ratio : 0.6;
     sh.outputs_pinned = host_pinned(io->h_pose) && host_pinned(io->h_mask);
+    sh.stereo_key = d_stereo_key;
 
     // ---- plan: the whole shard in one lane on the caller's stream, or chunks pipelined over two side streams ----
     std::vector<Chunk> chunks = plan_chunks(io, cfg);
@@ -981,5 +984,17 @@ extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *i
     g_timing[7] = n_launch;
     return SLAM_OK;
 }
+}  // namespace
+
+extern "C" int slam_track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *io, void *stream) try {
+    return track_pairs(cfg, io, nullptr, stream);
+}
 // a host failure (allocation, a worker's exception): wait for whatever the call had queued, on every stream it may have used
 SLAM_CATCH_ALL_WITH("slam_track_pairs", (void)hipDeviceSynchronize())
+
+extern "C" int slam_track_pairs_stereo_keys(const SlamTrackConfig *cfg, const SlamTrackIO *io, const uint32_t *d_stereo_key,
+                                            void *stream) try {
+    SLAM_REQUIRE(((uintptr_t)d_stereo_key & 3) == 0, "slam_track_pairs_stereo_keys: d_stereo_key must be 4-byte aligned");
+    return track_pairs(cfg, io, d_stereo_key, stream);
+}
+SLAM_CATCH_ALL_WITH("slam_track_pairs_stereo_keys", (void)hipDeviceSynchronize())

@@ -127,8 +127,11 @@ class ShardTracker:
             io.h_mask = self.h_mask.data_ptr() + a * (self.n_max // 64) * 8
             io.d_workspace, io.d_workspace_bytes = self.d_ws.data_ptr(), self.d_ws_bytes
             io.h_workspace, io.h_workspace_bytes = self.h_ws.data_ptr(), self.h_ws_bytes
-            io.d_stereo_key = stereo_key.data_ptr() + lo * self.n_max * 4 if stereo_key is not None else None
-            _lib.check(L.slam_track_pairs(ctypes.byref(self._c), ctypes.byref(io), ops._stream()))
+            if stereo_key is None:
+                _lib.check(L.slam_track_pairs(ctypes.byref(self._c), ctypes.byref(io), ops._stream()))
+            else:
+                _lib.check(L.slam_track_pairs_stereo_keys(ctypes.byref(self._c), ctypes.byref(io),
+                                                          stereo_key.data_ptr() + lo * self.n_max * 4, ops._stream()))
             t1 = np.zeros(8)
             L.slam_track_last_timing(t1.ctypes.data)
             tm += t1

@@ -122,6 +122,12 @@ def test_track_pairs_rejects_bad_arguments_before_touching_the_gpu():
     assert rc == _lib.SLAM_E_INVALID and "pair 1" in msg and "outside" in msg
     with pytest.raises(_lib.SlamError):
         _lib.check(rc)
+    # the variant that takes the frames' stereo keys validates the same way, plus the key pointer's alignment
+    rc = L.slam_track_pairs_stereo_keys(ctypes.byref(cfg), ctypes.byref(io), addr + 2, None)
+    assert rc == _lib.SLAM_E_INVALID and "aligned" in L.slam_last_error_string().decode()
+    rc = L.slam_track_pairs_stereo_keys(ctypes.byref(cfg), ctypes.byref(io), addr, None)
+    assert rc == _lib.SLAM_E_INVALID and "pair 1" in L.slam_last_error_string().decode()
+    assert L.slam_track_pairs_stereo_keys(None, None, None, None) == _lib.SLAM_E_INVALID
 
 
 def test_the_package_never_touches_the_oracle_or_the_reference_tree():

@@ -281,7 +281,7 @@ def test_results_do_not_depend_on_chunk_plan():
 
 @pytest.mark.parametrize("method,rule", [("bf", "ocv_legacy"), ("bf", "mutual"), ("knn", "ocv_legacy")])
 def test_stereo_keys_brought_by_the_caller_give_the_results_of_the_call_that_matches_them_itself(method, rule):
-    """SlamTrackIO::d_stereo_key (phase 2 of the multi-GPU loop-closure split, DESIGN 6): with the frames' stereo keys
+    """slam_track_pairs_stereo_keys (phase 2 of the multi-GPU loop-closure split): with the frames' stereo keys
     computed beforehand (pipeline.stereo_keys = slam_match_hamming_batched on every (left, right) pair) the call launches
     the temporal problems alone and must return what it returns when it matches the stereo pairs itself, bit for bit --
     one lane and chunked, consecutive pairs and a loop-closure-shaped list; the right images' descriptors are then not
