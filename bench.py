@@ -20,6 +20,7 @@ torch.distributed.run); under an external launcher (RANK set) it is one of the r
 from __future__ import annotations
 
 import argparse
+import dataclasses
 import json
 import os
 import socket
@@ -231,7 +232,8 @@ def trajectory_leg(args, rk: Rank, scaling: str):
     rel_buf[0] = np.eye(3, 4)                                 # the first camera (M1)
 
     def step():
-        res = trk.run(d_desc, d_xy, d_count, f0, f1, seeds, unpack_mask=False)
+        # results stay where the library wrote them (page-locked host memory); the step consumes them before the next run
+        res = trk.run(d_desc, d_xy, d_count, f0, f1, seeds, unpack_mask=False, copy=False)
         # the one exchange of the path: relative poses + counters to every rank (RCCL all-gather over xGMI)
         rel_all, _ = sdist.gather_shard_results(res.pose, res.stats, pairs_total)
         glob = None
@@ -255,6 +257,8 @@ def trajectory_leg(args, rk: Rank, scaling: str):
         stage_ms.append(res.timing_ms.copy())
     rk.fence()
     elapsed = rk.max_over_ranks(time.perf_counter() - t0)
+    # the last step's results, detached from the tracker's output buffers (later legs run the tracker again)
+    res = dataclasses.replace(res, pose=res.pose.copy(), stats=res.stats.copy(), mask=res.mask.copy())
     return dict(elapsed=elapsed, pairs_total=pairs_total, match_ms=match_ms, stage_ms=stage_ms, res=res, glob=glob, seq=seq,
                 desc=desc, xy=xy, count=count, trk=trk, f0=f0, f1=f1, seeds=seeds, gen_s=gen_s, F=F, P=P, n_max=n_max,
                 scaling=scaling)

@@ -86,11 +86,14 @@ class ShardTracker:
         self.h_mask = torch.empty((n_pairs, n_max // 64), dtype=torch.int64).pin_memory()
 
     def run(self, desc: torch.Tensor, xy: torch.Tensor, count: torch.Tensor, pair_f0: np.ndarray, pair_f1: np.ndarray,
-            seeds: np.ndarray, unpack_mask: bool = True, stereo_key: torch.Tensor | None = None) -> ShardResult:
+            seeds: np.ndarray, unpack_mask: bool = True, stereo_key: torch.Tensor | None = None,
+            copy: bool = True) -> ShardResult:
         """desc uint8[2F, n_max, 64], xy float32[2F, n_max, 2], count int32[2F] on the device (image 2f = left of
         frame f, 2f+1 = right); pair_f0/f1 int32[P] frame indices; seeds uint32[P] (np.random.seed per pair).
         stereo_key (optional) int32[F, n_max] on the device: the frames' stereo keys computed earlier (`stereo_keys`,
-        possibly on another rank); the call then matches only the temporal problems and reads no right-image descriptor."""
+        possibly on another rank); the call then matches only the temporal problems and reads no right-image descriptor.
+        copy=False: the result's host arrays are views of the tracker's page-locked output buffers (where the library wrote
+        them), valid until this tracker's next run -- for callers that consume a shard's results before they start the next."""
         F = desc.shape[0] // 2
         P = len(pair_f0)
         if F > self.n_frames or P > self.n_pairs or desc.shape[1] != self.n_max:
@@ -135,12 +138,14 @@ class ShardTracker:
             t1 = np.zeros(8)
             L.slam_track_last_timing(t1.ctypes.data)
             tm += t1
-        pose = self.h_pose[:P].numpy().reshape(P, 3, 4).copy()
-        stats = self.h_stats[:P].numpy().copy()
+        pose = self.h_pose[:P].numpy().reshape(P, 3, 4)
+        stats = self.h_stats[:P].numpy()
         if unpack_mask:
             mask = ops.mask_words_to_bool(self.h_mask[:P].numpy(), self.n_max)
         else:
-            mask = self.h_mask[:P].numpy().copy()
+            mask = self.h_mask[:P].numpy()
+        if copy:
+            pose, stats, mask = pose.copy(), stats.copy(), (mask if unpack_mask else mask.copy())
         return ShardResult(pose=pose, stats=stats, mask=mask, tracked_kp=self.tracked_kp[:P], timing_ms=tm)
 
 

@@ -314,6 +314,25 @@ def test_stereo_keys_brought_by_the_caller_give_the_results_of_the_call_that_mat
         ShardTracker(F, F - 1, n_max, hp).run(d_desc, d_xy, d_count, *consecutive_pairs(F), seeds[:F - 1], stereo_key=keys[:-1])
 
 
+def test_results_as_views_of_the_output_buffers_equal_the_copies():
+    """ShardTracker.run(copy=False) hands out the page-locked buffers the library wrote (what bench.py's step consumes);
+    same contents as the default copies, and owned by the tracker: the next run rewrites them."""
+    F = 12
+    cfg = SynthConfig(n_frames=F, n_features=400, seed=8, ragged=True)
+    desc, xy, count = SynthSequence(cfg).frames(0, F)
+    n_max = cfg.n_max
+    args = (dev(desc.reshape(2 * F, n_max, 64)), dev(xy.reshape(2 * F, n_max, 2)), dev(count.reshape(2 * F)))
+    f0, f1 = consecutive_pairs(F)
+    trk = ShardTracker(F, F - 1, n_max)
+    a = trk.run(*args, f0, f1, 5 + np.arange(F - 1), unpack_mask=False)
+    v = trk.run(*args, f0, f1, 5 + np.arange(F - 1), unpack_mask=False, copy=False)
+    assert np.array_equal(a.pose, v.pose, equal_nan=True) and np.array_equal(a.stats, v.stats) and np.array_equal(a.mask, v.mask)
+    assert not v.pose.flags.owndata and a.pose.flags.owndata
+    kept = v.pose.copy()
+    trk.run(*args, f0, f1, 900 + np.arange(F - 1), unpack_mask=False, copy=False)      # other seeds: other winners
+    assert np.array_equal(a.pose, kept, equal_nan=True) and not np.array_equal(v.pose, kept, equal_nan=True)
+
+
 def test_a_pairs_pose_does_not_depend_on_the_size_of_its_launch():
     """The refit's summation order (wavefronts per pair, LDS or global walk) is a function of the pair's own layout,
     never of how many pairs share the launch: round 2 switched both on the launch size (768 / 256 pairs), so a pair's pose
