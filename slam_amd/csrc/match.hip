@@ -205,7 +205,14 @@ __global__ __launch_bounds__(BLOCK) void allpairs_top2_kernel(MatchBatch mb) {
 
     // B range of this split, in whole tiles
     const int tiles_b = (nb + TILE_B - 1) / TILE_B;
-    const int tiles_per_split = (tiles_b + mb.nsplit - 1) / mb.nsplit;
+    // Front-loaded splits: the workgroups of the LAST split are dispatched last (blockIdx.y is the slow index), and a
+    // launch ends with about half a "round" of its last workgroups running on a half-empty chip.  One more tile for
+    // every earlier split leaves the last one short -- 16 tiles over 3 splits: 7, 7, 2 instead of 6, 6, 4 -- so the
+    // ragged end of a small grid is made of short workgroups (when that leaves the last split a tile at all).
+    int tiles_per_split = (tiles_b + mb.nsplit - 1) / mb.nsplit;
+#ifndef SLAM_SPLIT_EVEN
+    if (mb.nsplit > 1 && (mb.nsplit - 1) * (tiles_per_split + 1) < tiles_b) ++tiles_per_split;
+#endif
     const int tb0 = split * tiles_per_split;
     const int tb1 = min(tiles_b, tb0 + tiles_per_split);
 
