@@ -76,6 +76,39 @@ def test_two_rank_gather_equals_single_process():
         assert set(stats[:, 1]) == {0, 19}                            # which rank's frame range produced each pair
 
 
+def _worker_digest(rank, world, port, n_frames, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rel, glob, stats = sdist.run_sharded(n_frames, _run_shard)
+    q.put((rank, rel.shape, float(np.abs(rel).sum()), float(np.abs(glob).sum()), stats[:, 0].copy(), np.unique(stats[:, 1])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_on_the_bench_sequence_shape():
+    """BASELINE configs[2] at N = 8, the shape the driver's scaling run has: 3450 frames = 3449 pairs in blocks of 432
+    (the last rank 425), one halo frame per rank, one all-gather of the 128-byte rows; every rank ends with the whole
+    sequence's poses in pair order and the same composed trajectory (stand-in per-shard compute, gloo on the CPU)."""
+    n_frames, world = 3450, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_digest, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want_pose, want_stats = _run_shard(0, n_frames, 0)
+    want_rel = np.concatenate([np.eye(3, 4)[None], want_pose])
+    want_glob = compose_global(want_rel)
+    for rank, shape, rel_sum, glob_sum, pair_ids, starts in got:
+        assert shape == (n_frames, 3, 4) and np.array_equal(pair_ids, np.arange(n_frames - 1))
+        assert rel_sum == float(np.abs(want_rel).sum()) and glob_sum == float(np.abs(want_glob).sum())
+        assert starts.tolist() == [432 * r for r in range(8)]          # each pair came from the rank that owns it
+
+
 def _ragged_worker(rank, world, port, n_units, n_frames, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
