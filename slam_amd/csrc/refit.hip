@@ -138,11 +138,15 @@ __device__ __forceinline__ Pose apply_step(const Pose &P, const double (&d)[6]) 
 }
 
 constexpr int MAX_EVAL = 60;
-// Stopping rule: the solve ends with the first trial step whose relative size is below FLT_EPSILON -- CvLevMarq's own
-// criterion for cv2.solvePnP(ITERATIVE) (the reference's refit, utils/utills.py:562-563) -- whether that step is accepted
-// (it is applied) or rejected (the pose stays).  SLAM_REFIT_STEP2 is the square of that relative size.  The iteration
-// converges quadratically on top of a damping that is down to 1e-3 x 0.1^k by step k, so the pose after an accepted
-// step of relative size s is within ~max(1e-5 s, s^2) of the minimiser: ~1e-12 here.
+// Stopping rule: the solve ends with the first trial step whose relative size is below FLT_EPSILON -- the size at which
+// CvLevMarq, cv2.solvePnP(ITERATIVE)'s solver and so the reference's refit (utils/utills.py:562-563), ends after an
+// ACCEPTED step -- whether that step is accepted (it is applied) or rejected (the pose stays; CvLevMarq itself goes on
+// raising its damping there, to the same pose).  SLAM_REFIT_STEP2 is the square of that relative size.  The rule only
+// applies while the damping is at most 1 (the Marquardt-scaled step is then within a factor 2 of the Gauss-Newton
+// step, so a tiny step means a tiny distance to the minimum, not a heavily damped one); under heavier damping, i.e.
+// after three or more rejections in a row, the solve goes on as before.  The iteration converges quadratically on top
+// of a damping that is down to 1e-3 x 0.1^k by step k, so the pose after an accepted step of relative size s is within
+// ~max(1e-5 s, s^2) of the minimiser: ~1e-12 here.
 // Measured on bench-shaped pairs (tools/refit_evals_hist.py, a probe build counting trial steps): rounds 1-3 stopped on
 // an ACCEPTED step below 1e-9 only and went on, after a rejected one, until the step was below 1e-15 relative -- at the
 // minimum the cost comparison is rounding noise, so half the pairs took 5 to 16 trial steps (mean 6.3) for a pose that
@@ -381,16 +385,17 @@ __global__ __launch_bounds__(RW * 64) void refit_kernel(Mat33 K, const double *X
 #pragma unroll
             for (int a = 0; a < 6; ++a) dn += d[a] * d[a];
             pn = 1.0 + P.t[0] * P.t[0] + P.t[1] * P.t[1] + P.t[2] * P.t[2];
+            const bool light = lambda <= 1.0;          // the step just tried is within a factor 2 of the Gauss-Newton step
             if (c2 <= cost) {
                 P = Q;
-                const bool tiny = dn <= SLAM_REFIT_STEP2 * pn || (cost - c2) <= 1e-15 * cost;
+                const bool tiny = dn <= (light ? SLAM_REFIT_STEP2 : 1e-18) * pn || (cost - c2) <= 1e-15 * cost;
                 cost = c2;
                 lambda = fmax(lambda * 0.1, 1e-16);
                 stepped = true;
                 if (tiny) done = true;
             } else {
                 lambda *= 10.0;
-                if (lambda > 1e16 || dn <= SLAM_REFIT_REJECT_STEP2 * pn) done = true, stepped = true;
+                if (lambda > 1e16 || dn <= (light ? SLAM_REFIT_REJECT_STEP2 : 1e-30) * pn) done = true, stepped = true;
             }
         }
     }
