@@ -208,6 +208,20 @@ int slam_score_hypotheses(const double *h_K, const double *h_M2, const double *d
                           const int32_t *d_count, int n_seg, int seg_stride, const double *d_pose,
                           const uint8_t *d_status, int n_hyp, double thr, int32_t *d_inlier_count, uint64_t *d_mask,
                           void *stream);
+/* The same counts with a single-precision pre-classification (rectified rigs: K = [fx 0 cx; 0 fy cy; 0 0 1],
+ * M2 = [I | (tx, 0, 0)]; any other rig, or thr outside [1e-3, 1e6], takes the kernels of slam_score_hypotheses).
+ * A caller that scores many hypothesis batches against the same points (the RANSAC rounds of slam_track_pairs do)
+ * converts them once with slam_score_pack_points -- d_packed float32 [n_seg][seg_stride][8] (16-byte aligned),
+ * d_scale float32 [n_seg] -- and passes both here next to the float64 points and float32 observations they were made
+ * from.  A test is decided in single precision only when it is farther from the radius than a rigorous bound on
+ * everything single precision can have lost; the rest (about one test in a million) goes through the float64
+ * arithmetic of slam_score_hypotheses, so d_inlier_count is identical (score.hip has the error analysis). */
+int slam_score_pack_points(const double *d_X, const float *d_xy1, const int32_t *d_count, int n_seg, int seg_stride,
+                           float *d_packed, float *d_scale, void *stream);
+int slam_score_hypotheses_packed(const double *h_K, const double *h_M2, const double *d_X, const float *d_xy1,
+                                 const float *d_packed, const float *d_scale, const int32_t *d_count, int n_seg,
+                                 int seg_stride, const double *d_pose, const uint8_t *d_status, int n_hyp, double thr,
+                                 int32_t *d_inlier_count, void *stream);
 /* float64 observations, one segment, one pose (drop-in `consensus_match`) */
 int slam_consensus_match_f64(const double *h_K, const double *h_M2, const double *h_pose, const double *d_X,
                              const double *d_left1, const double *d_right1, int n, double thr, uint8_t *d_mask,

@@ -79,6 +79,9 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p]),
     "slam_score_hypotheses": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
                                       c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p]),
+    "slam_score_pack_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "slam_score_hypotheses_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                             c_int, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p]),
     "slam_consensus_match_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double,
                                          c_void_p, c_void_p]),
     "slam_refit_pnp": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,

@@ -28,7 +28,13 @@ int slam_launch_p3p(const Mat33 &K, const double *d_X, const void *d_xy1, int xy
 int slam_launch_score(const Mat33 &K, const Mat34 &M2, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count,
                       const int32_t *d_seg_of, int n_rows, int seg_stride, const double *d_pose,
                       const uint8_t *d_status, int n_hyp, double thr, int32_t *d_inlier_count, uint64_t *d_mask,
-                      hipStream_t st, const int32_t *d_gate = nullptr);
+                      hipStream_t st, const int32_t *d_gate = nullptr, const float *d_packed = nullptr,
+                      const float *d_scale = nullptr);
+// d_packed / d_scale (optional, counting on a rectified rig): the points' single-precision records written by
+// slam_launch_pack_points for the same d_X / d_xy1 / d_count -- [n_seg][seg_stride][8] floats and [n_seg] floats; the
+// counts are the same, the scoring kernels classify in single precision first (score.hip).
+int slam_launch_pack_points(const double *d_X, const float *d_xy1, const int32_t *d_count, int n_seg, int seg_stride,
+                            float *d_packed, float *d_scale, hipStream_t st);
 int slam_launch_refit(const Mat33 &K, const double *d_X, const void *d_xy1, int xy_f64, const int32_t *d_count, int n_seg,
                       int seg_stride, const uint64_t *d_mask_words, const double *d_pose0, double *d_pose,
                       uint8_t *d_status, hipStream_t st, const int32_t *d_gate = nullptr);

@@ -51,6 +51,7 @@ struct Buffers {
     int32_t *setup, *prob_q, *prob_t, *pair_f0, *pair_f1, *order, *tcount, *aux;
     float *xy0, *xy1;
     double *X;
+    float *packed, *scale;          // the points' single-precision records for the scoring kernels (score.hip)
     int32_t *sample0, *produced0, *cnt0, *best_idx, *best_cnt;
     double *pose0, *best_pose, *refit_pose;
     uint8_t *status0, *best_status, *refit_status;
@@ -133,6 +134,8 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
     b.xy0 = d.take<float>(Ps * N * 4);
     b.xy1 = d.take<float>(Ps * N * 4);
     b.X = d.take<double>(Ps * N * 3);
+    b.packed = d.take<float>(Ps * N * 8);
+    b.scale = d.take<float>(Ps);
     b.sample0 = d.take<int32_t>(Ps * b.D0 * 4);
     b.pose0 = d.take<double>(Ps * b.D0 * 12);
     b.best_idx = d.take<int32_t>(Ps);
@@ -420,12 +423,14 @@ struct Lane {
         if (rc) return rc;
         SLAM_HIP_CHECK(hipEventRecord(ev[3], st));
         // ---- 4. RANSAC round 0: D0 speculative draws for every pair ----
+        rc = slam_launch_pack_points(b.X, b.xy1, b.tcount, P, N, b.packed, b.scale, st);
+        if (rc) return rc;
         rc = slam_launch_draw_samples(b.seed, b.tcount, nullptr, nullptr, P, D0, b.sample0, b.produced0, st);
         if (rc) return rc;
         rc = slam_launch_p3p(sh.K, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.sample0, D0, 0, D0, b.pose0, b.status0, st);
         if (rc) return rc;
         rc = slam_launch_score(sh.K, sh.M2, b.X, b.xy1, 0, b.tcount, nullptr, P, N, b.pose0, b.status0, D0, sh.thr, b.cnt0,
-                               nullptr, st);
+                               nullptr, st, nullptr, b.packed, b.scale);
         if (rc) return rc;
         // device-side replay of round 0 (a prediction the host verifies in mid()), then ONE download of everything the
         // host replay reads, then -- speculatively, gated on "no pair wants another round" -- the winner's mask, the
@@ -549,7 +554,7 @@ struct Lane {
                                          b.poseR[s], b.statusR[s], st);
                 if (r2) return r2;
                 r2 = slam_launch_score(sh.K, sh.M2, b.X, b.xy1, 0, b.tcount, b.seg_of[s], rows, N, b.poseR[s], b.statusR[s],
-                                       n_eval, sh.thr, b.cntR[s], nullptr, st);
+                                       n_eval, sh.thr, b.cntR[s], nullptr, st, nullptr, b.packed, b.scale);
                 if (r2) return r2;
                 // the results go down on the copy stream, so the kernels of the next sub-batch (queued on `st` before the
                 // host waits for these) run under the copies instead of behind them: 5 bytes per hypothesis, ~0.1 ms of

@@ -200,6 +200,32 @@ def score_hypotheses(K, M2, X, xy1, count, pose, status, thr=4.0, want_mask=Fals
     return cnt, mask
 
 
+def score_pack_points(X, xy1, count):
+    """The points' single-precision records for score_hypotheses_packed: X float64[n_seg, stride, 3], xy1
+    float32[n_seg, stride, 4] -> (packed float32[n_seg, stride, 8], scale float32[n_seg])."""
+    n_seg, stride, _ = X.shape
+    if xy1.dtype != torch.float32:
+        raise TypeError("score_pack_points takes float32 observations")
+    packed = torch.empty((n_seg, stride, 8), dtype=torch.float32, device=X.device)
+    scale = torch.empty(n_seg, dtype=torch.float32, device=X.device)
+    check(_lib.lib().slam_score_pack_points(_dev(X, torch.float64), _dev(xy1, torch.float32), _dev(count, torch.int32), n_seg,
+                                            stride, _dev(packed), _dev(scale), _stream()))
+    return packed, scale
+
+
+def score_hypotheses_packed(K, M2, X, xy1, packed, scale, count, pose, status, thr=4.0):
+    """score_hypotheses' counts through the single-precision pre-classification (include/slam_amd.h)."""
+    K, M2 = _f64(K, (3, 3)), _f64(M2, (3, 4))
+    n_seg, stride, _ = X.shape
+    n_hyp = pose.shape[1]
+    cnt = torch.empty((n_seg, n_hyp), dtype=torch.int32, device=X.device)
+    check(_lib.lib().slam_score_hypotheses_packed(_host(K), _host(M2), _dev(X, torch.float64), _dev(xy1, torch.float32),
+                                                  _dev(packed, torch.float32), _dev(scale, torch.float32),
+                                                  _dev(count, torch.int32), n_seg, stride, _dev(pose, torch.float64),
+                                                  _dev(status, torch.uint8), n_hyp, float(thr), _dev(cnt), _stream()))
+    return cnt
+
+
 def consensus_match_f64(K, M2, T, X, left1, right1, thr):
     K, M2, T = _f64(K, (3, 3)), _f64(M2, (3, 4)), _f64(T, (3, 4))
     n = X.shape[0]

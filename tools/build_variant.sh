@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 obj=$root/build/obj_$tag
 mkdir -p $obj $root/tune
 for s in $root/slam_amd/csrc/*.hip $root/slam_amd/csrc/*.cpp; do
-  x=""; case $s in *.cpp) x="-x hip";; esac
+  x=""; case $s in *.cpp) x="-x hip";; *score.hip) x="-fno-slp-vectorize";; esac      # per-file flags as in __graft_entry__.py
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function "$@" $x -c $s -o $obj/$(basename $s).o &
 done
 wait
