@@ -51,8 +51,8 @@ VALU_SUSTAINED_BITOP3, VALU_SUSTAINED_BCNT = 61.09, 36.37
 # descriptor pairs/s if every instruction of a pair issued at its own measured sustained rate: 8 xor + 1 cmp, 8 bitop3, 8 bcnt
 MIX_CEILING_TPAIRS = 1.0 / (9 / VALU_SUSTAINED_TSLOTS + 8 / VALU_SUSTAINED_BITOP3 + 8 / VALU_SUSTAINED_BCNT)
 SURVEY_OPS_PER_PAIR = 80
-PMC_SUMMARY = os.path.join("profiles", "r3_pmc_summary.json")
-PMC_SUMMARY_FALLBACK = os.path.join("profiles", "r2_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r3_final2_pmc_summary.json")
+PMC_SUMMARY_FALLBACK = os.path.join("profiles", "r3_pmc_summary.json")
 
 
 def parse(argv=None):
