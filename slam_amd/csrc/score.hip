@@ -597,8 +597,8 @@ __global__ __launch_bounds__(SB) void score_f32_kernel(Mat33 K, Mat34 M2, const 
 }
 
 // score_lanes_kernel with the single-precision pre-classification: HL hypotheses per lane, the segment's records staged
-// through LDS in tiles of LTF points and read back as broadcasts (two ds_read_b128 per point feed 64 x HL tests; at one
-// hypothesis per lane the LDS return path, 128 B per clock, would set the pace, not the VALU).
+// through LDS in tiles of LTF points and read back as broadcasts (two ds_read_b128 per point feed 64 x HL tests; one
+// hypothesis per lane measured faster than two: 1.34 against 1.20 T tests/s, occupancy and grid fill).
 // Undecided tests are not rare enough to be an afterthought: a hypothesis near the truth puts many points a few pixels
 // from their observations, and about one of its tests in a thousand falls inside the single-precision band (+-1e-3 px).
 // They are queued per wavefront in LDS as (lane, hypothesis slot, point) and settled COOPERATIVELY: each lane takes one
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(SB) void score_f32_kernel(Mat33 K, Mat34 M2, const 
 // against 15.7 for the loop-closure configuration's 570-point segments, but 5.9 ms against 3.3 on 6000-point segments,
 // whose 190 KB of records stream through the 16 KB scalar cache; scalar loads return out of order, so a wavefront
 // cannot keep more than one batch in flight.)
-constexpr int LTF = 512;      // points per LDS tile (32 bytes each: 16 KB)
+constexpr int LTF = 256;      // points per LDS tile (32 bytes each: 8 KB; with the queue 17 KB per workgroup)
 #ifndef SLAM_F32_HL
 #define SLAM_F32_HL 1
 #endif
@@ -618,10 +618,15 @@ constexpr int HL = SLAM_F32_HL;   // hypotheses per lane
 #define SLAM_F32_PU 4
 #endif
 constexpr int PU = SLAM_F32_PU;   // points per step of the scan
-constexpr int WQCAP = 1024;       // queued tests per wavefront; a step adds at most 64 * PU * HL
+// registers capped for five wavefronts per SIMD (the few spills land in the set-up and the drain): 1.33 -> 1.40 T tests/s;
+// six spill inside the drain (0.39 where drains are frequent)
+#ifndef SLAM_F32_WPE
+#define SLAM_F32_WPE 5
+#endif
+constexpr int WQCAP = 512;        // queued tests per wavefront; a step adds at most 64 * PU * HL
 static_assert(64 * PU * HL <= WQCAP / 2, "a step must fit the queue's reserve");
 
-__global__ __launch_bounds__(SB) void score_lanes_f32_kernel(Mat33 K, Mat34 M2, const double *X, const float4 *xy1,
+__global__ __launch_bounds__(SB) __attribute__((amdgpu_waves_per_eu(SLAM_F32_WPE, 8))) void score_lanes_f32_kernel(Mat33 K, Mat34 M2, const double *X, const float4 *xy1,
                                                              const float4 *__restrict__ packed, const float *scale,
                                                              const int *count, const int *seg_of, int n_rows, int groups,
                                                              int seg_stride, const double *pose, const uint8_t *status,
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(SB) void score_lanes_f32_kernel(Mat33 K, Mat34 M2, 
         if (!wave_live) continue;
         // PU points per step: their LDS reads are in flight together, the PU x HL tests form one block of independent
         // instruction chains, and the undecided ones are queued once per step, one branch instead of PU x HL
-        auto step = [&](int i, auto pu_tag) {
+        auto step = [&](int i, auto pu_tag) -> bool {
             constexpr int PU_ = decltype(pu_tag)::value;
             float4 a[PU_], b[PU_];
 #pragma unroll
@@ -728,12 +733,16 @@ __global__ __launch_bounds__(SB) void score_lanes_f32_kernel(Mat33 K, Mat34 M2, 
                         wq[wave][slot] = (unsigned)lane << 24 | (unsigned)(t % HL) << 16 | (unsigned)(base + i + t / HL);
                     }
                 __builtin_amdgcn_wave_barrier();
-                if (__builtin_amdgcn_readfirstlane(wq_n[wave]) > WQCAP / 2) drain();
+                return true;
             }
+            return false;
         };
+        // the queue is drained between steps (no point record is live then) once it is half full
         int i = 0;
-        for (; i + PU <= m; i += PU) step(i, std::integral_constant<int, PU>());
-        for (; i < m; ++i) step(i, std::integral_constant<int, 1>());
+        for (; i + PU <= m; i += PU)
+            if (step(i, std::integral_constant<int, PU>()) && __builtin_amdgcn_readfirstlane(wq_n[wave]) > WQCAP / 2) drain();
+        for (; i < m; ++i)
+            if (step(i, std::integral_constant<int, 1>()) && __builtin_amdgcn_readfirstlane(wq_n[wave]) > WQCAP / 2) drain();
     }
     if (wave_live) drain();
 #pragma unroll
