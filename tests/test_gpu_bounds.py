@@ -149,6 +149,11 @@ def test_stages_stay_inside_their_buffers(guard):
         cnt_m, mask = ops.score_hypotheses(K_KITTI, M2_KITTI, X, xy1, tcount, pose, status, 4.0, want_mask=True)
         guard.check(f"slam_score_hypotheses masks {n_hyp}")
         assert torch.equal(cnt, cnt_m) and int(cnt[1:].abs().sum()) == 0
+        packed, scale = ops.score_pack_points(X, xy1, tcount)
+        guard.check(f"slam_score_pack_points {n_hyp}")
+        cnt_p = ops.score_hypotheses_packed(K_KITTI, M2_KITTI, X, xy1, packed, scale, tcount, pose, status, 4.0)
+        guard.check(f"slam_score_hypotheses_packed {n_hyp}")
+        assert torch.equal(cnt, cnt_p)
     best = int(cnt[0].argmax())
     words = mask[:, best].contiguous()
     pose1, st = ops.refit_pnp(K_KITTI, X, xy1, tcount, words, pose[:, best].contiguous())
