@@ -326,8 +326,8 @@ __global__ __launch_bounds__(SB) void score_lanes_kernel(Mat33 K, Mat34 M2, cons
 // The FP64 classification above costs ~24 half-rate instructions per point and hypothesis.  Almost every point is far
 // from the 4-pixel circle, so a single-precision evaluation WITH A RIGOROUS ERROR BOUND decides it: the point counts as
 // inside (outside) only if it is inside (outside) by more than everything single precision can have lost; the rest --
-// about one test in a million on bench data -- is settled by the FP64 functions above, so the counts stay the
-// reference's bit for bit.  ~28 full-rate instructions per test instead of ~24 half-rate ones + 4 compares.
+// about one test in a thousand on a hypothesis near the truth, far fewer on a random one -- is settled by the FP64
+// functions above, so the counts stay the reference's bit for bit.  ~28 full-rate instructions per test instead of ~24 half-rate ones + 4 compares.
 //
 // Quantities: u = 2^-24.  Rounding x, y, z and the matrix to float and evaluating
 //     h = fma(x, p0, fma(y, p1, fma(z, p2, p3)))
@@ -343,6 +343,8 @@ __global__ __launch_bounds__(SB) void score_lanes_kernel(Mat33 K, Mat34 M2, cons
 // squares: < 1e-6 together) are covered by the factors 1 -+ 2e-6 on the radius.  Decision:
 //     inside  iff  q < L |L|  in both cameras,  L = thr |hz| (1 - 2e-6) - E      (L |L| < 0 when L < 0: never inside)
 //     outside iff  q > U^2    in one camera,    U = thr |hz| (1 + 2e-6) + E
+// (an intermediate that overflows has H > 3.4e38, hence E > 1e32 and U^2 = inf: nothing is greater, undecided; with
+// hz = +-inf the left-hand sides are inf or NaN, never less than L |L|)
 // A decisive answer is therefore at least 1e-7 (relative) away from the radius, where the FP64 classification (band
 // 1e-9) and the reference's own arithmetic agree with exact arithmetic.  Anything irregular is undecided by
 // construction: a NaN or infinity anywhere makes both comparisons false; s = NaN marks a point with a non-finite or
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(SB) void score_f32_kernel(Mat33 K, Mat34 M2, const 
     const float thrf = (float)thr;
 
     // Set-up: lane j builds hypothesis h0 + j (the FP64 matrices, then the single-precision constants), so the HW
-    // set-ups cost one; the constants then move to scalar registers with v_readlane.
+    // set-ups cost one; v_readlane then hands every lane all HW sets of constants (lane_to_all).
     HypF H[HW];
     bool live[HW];
     bool any_live = false;
@@ -516,8 +518,10 @@ __global__ __launch_bounds__(SB) void score_f32_kernel(Mat33 K, Mat34 M2, const 
 #pragma unroll
     for (int j = 0; j < HW; ++j) total[j] = 0;
     const float4 *pk = packed + (size_t)seg * seg_stride * 2;
-    // Undecided tests (about one in a million) are queued in LDS, per wavefront, and settled in FP64 after the scan, so
-    // that the scan itself holds nothing but the single-precision constants: (point << 3 | hypothesis slot).
+    // Undecided tests (a handful per wavefront: HW x n tests at one in a thousand or fewer) are queued in LDS, per
+    // wavefront, and settled in FP64 after the scan, so that the scan itself holds nothing but the single-precision
+    // constants: (point << 3 | hypothesis slot).  Overflow and irregular values (an infinite intermediate has H > 3e38,
+    // hence E > 1e32 and U^2 = inf: undecided) are covered: see the recount below and the header.
     __shared__ int q_cnt[SB / 64];
     __shared__ int q_ent[SB / 64][QCAP];
     if (lane == 0) q_cnt[wave] = 0;
