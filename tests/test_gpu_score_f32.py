@@ -90,8 +90,8 @@ def test_points_inside_the_single_precision_band_are_settled_in_fp64(H):
     """Every point of the segment lies within a few 1e-5 px of the radius for hypothesis 0 (the observations are the
     hypothesis' own projections pushed out by 4 px, rounded to float32: +-3e-5 px of rounding decides which side), so every
     test of that hypothesis is undecided in single precision: the LDS queue of the wavefront kernels overflows (more
-    than 64 per wavefront) and so do the lane kernel's four pending slots -- their recount paths run.  Hypotheses 1, 2:
-    the same with a sprinkling of such points (the queue / the pending slots themselves)."""
+    than 64 per wavefront: their FP64 recount runs) and the lane kernel's per-wavefront queue is drained again and again.
+    Hypotheses 1, 2: the same with a sprinkling of such points (queues that do not overflow)."""
     rng = np.random.default_rng(7 + H)
     n, stride = 900, 960
     X, _, _ = scene(rng, n)
@@ -202,3 +202,33 @@ def test_packed_path_on_a_general_rig_takes_the_fp64_kernels():
     Xs[0, :n], xy1[0, :n] = X, np.hstack([l1, r1])
     ref, got = both_paths(Kg, M2g, Xs, xy1, [n], Ts[None], np.ones((1, H), np.uint8))
     assert np.array_equal(ref[0], want) and np.array_equal(got[0], want)
+
+
+@pytest.mark.parametrize("H", [6, 300])
+def test_single_precision_overflow_and_cancellation_stay_undecided(H):
+    """KITTI rig: points far enough out that fx * x overflows float32 while x itself does not (hx = inf in single
+    precision, q = inf: must not read as "outside" when the exact distance is inside), and points whose homogeneous
+    coordinates cancel (a camera rotated so that hz is a small difference of large terms).  Counts against the oracle."""
+    rng = np.random.default_rng(31 + H)
+    pts = []
+    for e in (1.0, 1e20, 1e30, 1e34, 1e35, 3e35, 1e36, 1e37, 2.5e38):
+        for k in range(6):
+            d = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.1, 0.1), 1.0]) * rng.uniform(5, 50)
+            pts.append(d * e)
+    X = np.array(pts)
+    n, stride = len(X), 64
+    pl = orc.project(X, orc.K @ T0)
+    pr = orc.project(X, orc.K @ orc.compose(T0, orc.M2))
+    off = rng.uniform(-5, 5, (n, 2))                       # about half inside the 4 px radius
+    l1, r1 = (pl + off).astype(np.float32), (pr + off).astype(np.float32)
+    Ts = poses(rng, H)
+    Ts[0] = T0
+    # a camera looking sideways: the depth of a point straight ahead is a small difference of large terms
+    Ts[1] = np.hstack([orc.rodrigues_vec_to_mat(np.array([0.0, np.pi / 2 - 1e-7, 0.0])), np.array([[0.0], [0.0], [1e-3]])])
+    want = oracle_counts(orc.K, orc.M2, X, l1, r1, Ts)
+    Xs, xy1 = np.zeros((1, stride, 3)), np.zeros((1, stride, 4), np.float32)
+    Xs[0, :n], xy1[0, :n] = X, np.hstack([l1, r1])
+    ref, got = both_paths(orc.K, orc.M2, Xs, xy1, [n], Ts[None], np.ones((1, H), np.uint8))
+    assert np.array_equal(ref[0], want)
+    assert np.array_equal(got[0], want)
+    assert 10 < want[0] < n - 5
