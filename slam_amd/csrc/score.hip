@@ -857,6 +857,7 @@ int slam_launch_pack_points(const double *d_X, const float *d_xy1, const int32_t
                             float *d_packed, float *d_scale, hipStream_t st) {
     if (n_seg <= 0 || seg_stride <= 0) return SLAM_OK;
     SLAM_REQUIRE(d_X && d_xy1 && d_count && d_packed && d_scale, "slam_score_pack_points: null pointer");
+    SLAM_REQUIRE((((uintptr_t)d_packed | (uintptr_t)d_xy1) & 15) == 0, "slam_score_pack_points: d_xy1 and d_packed must be 16-byte aligned");
     hipLaunchKernelGGL(pack_points_kernel, dim3(n_seg), dim3(256), 0, st, d_X, (const float4 *)d_xy1, d_count, seg_stride,
                        (float4 *)d_packed, d_scale);
     SLAM_HIP_CHECK(hipGetLastError());
@@ -874,7 +875,8 @@ extern "C" int slam_score_hypotheses_packed(const double *h_K, const double *h_M
                                             double thr, int32_t *d_inlier_count, void *stream) {
     SLAM_REQUIRE(h_K && h_M2 && d_X && d_xy1 && d_packed && d_scale && d_count && d_pose && d_status && d_inlier_count,
                  "slam_score_hypotheses_packed: null pointer");
-    SLAM_REQUIRE((((uintptr_t)d_packed) & 15) == 0, "slam_score_hypotheses_packed: d_packed must be 16-byte aligned");
+    SLAM_REQUIRE((((uintptr_t)d_packed | (uintptr_t)d_xy1) & 15) == 0, "slam_score_hypotheses_packed: d_xy1 and d_packed must be 16-byte aligned");
+    SLAM_REQUIRE(n_seg >= 0 && seg_stride >= 0 && n_hyp >= 0, "slam_score_hypotheses_packed: negative size");
     Mat33 K;
     Mat34 M2;
     for (int i = 0; i < 9; ++i) K.m[i] = h_K[i];
