@@ -128,17 +128,34 @@ void RansacReplay::consume(const RansacParams &p, int n_points, const uint8_t *s
     while (!finished) {
         // wants_more(), with the log/pow of the estimate recomputed only when the outlier ratio changed (pairs stuck at
         // the 0.99 clip run hundreds of iterations on one value)
-        bool more;
+        bool more = false;
         if (p.fixed_iterations > 0) {
             more = it < p.fixed_iterations;
         } else if (outliers_perc == 0.0) {
             more = false;
         } else {
-            if (est_for != outliers_perc) {
-                est = std::log(1.0 - p.prob) / std::log(1.0 - std::pow(1.0 - outliers_perc, 4.0));
-                est_for = outliers_perc;
+            // The estimate grows with the outlier ratio, so the value cached for a ratio r0 settles the test for every
+            // ratio on the far side of r0 from the answer: r >= r0 and it < est(r0) -> more; r <= r0 and it >= est(r0)
+            // -> no more (a margin of 1e-9 relative against the rounding of log / pow, which is ~1e-16).  A pair stuck
+            // near one ratio -- unrelated frames run a thousand iterations around 0.93 -- then recomputes log and pow
+            // only when its ratio reaches a new minimum, not at every iteration.  Same decisions, bit for bit.
+            bool known = false;
+            if (est_for > 0.0) {
+                if (outliers_perc >= est_for && (double)it < est * (1.0 - 1e-9)) {
+                    more = (double)it < p.max_iterations;
+                    known = true;
+                } else if (outliers_perc <= est_for && (double)it >= est * (1.0 + 1e-9)) {
+                    more = false;
+                    known = true;
+                }
             }
-            more = (double)it < est && (double)it < p.max_iterations;
+            if (!known) {
+                if (est_for != outliers_perc) {
+                    est = std::log(1.0 - p.prob) / std::log(1.0 - std::pow(1.0 - outliers_perc, 4.0));
+                    est_for = outliers_perc;
+                }
+                more = (double)it < est && (double)it < p.max_iterations;
+            }
         }
         if (!more) {
             finished = true;

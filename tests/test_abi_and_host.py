@@ -172,6 +172,47 @@ def _reference_loop(n, status, cnt, prob=0.9999, max_iterations=1e3):
     return it, d, best, False
 
 
+def test_ransac_replay_random_sequences_incl_estimates_near_the_iteration_count():
+    """The replay skips recomputing the loop's estimate where the cached one settles the test by monotonicity (an
+    outlier ratio on the far side of the cached ratio from the answer): 400 random supporter sequences whose estimate
+    ends anywhere between a handful and the 1000-iteration cap -- drifting, oscillating and step-changing inlier rates,
+    so the ratio crosses the cached one in both directions close to where the loop stops -- against the literal loop."""
+    import ctypes
+    rng = np.random.default_rng(2024)
+    L = _lib.lib()
+    n, D = 700, 2600
+    stops = []
+    for case in range(400):
+        rate = rng.uniform(0.3, 0.98)                                    # inlier share of a good hypothesis
+        good = rng.random(D) < rng.choice([1.0, 0.95, rng.uniform(0.3, 1.0)])
+        kind = case % 4
+        t = np.arange(D)
+        if kind == 1:
+            rate = rate * (1 + 0.4 * np.sin(t / rng.uniform(2, 60)))     # oscillating
+        elif kind == 2:
+            rate = rate * np.where(t < rng.integers(3, 200), rng.uniform(0.2, 1.0), 1.0)   # a step
+        elif kind == 3:
+            rate = rate * np.linspace(1.0, rng.uniform(0.3, 1.5), D)     # drifting
+        cnt = np.clip(np.where(good, n * rate + rng.normal(0, 8, D), rng.integers(0, 12, D)), 0, n).astype(np.int32)
+        status = (rng.random(D) > rng.choice([0.0, 0.1, 0.5])).astype(np.uint8)
+        want = _reference_loop(n, status, cnt)
+        if want[3]:
+            continue
+        stops.append(want[0])
+        for batch in (37, D):
+            st = _lib.SlamRansacState()
+            L.slam_ransac_state_init(ctypes.byref(st))
+            begin = 0
+            while not st.finished:
+                end = min(begin + batch, D)
+                assert L.slam_ransac_replay(ctypes.byref(st), n, status[begin:end].ctypes.data, cnt[begin:end].ctypes.data,
+                                            begin, end, 0.9999, 1e3, 0, 0) == 0
+                begin = end
+            assert (st.it, st.draws, st.best_draw) == want[:3], (case, batch)
+    stops = np.array(stops)
+    assert len(stops) > 300 and (stops < 20).sum() > 30 and ((stops > 50) & (stops < 1000)).sum() > 30 and (stops == 1000).sum() > 10
+
+
 @pytest.mark.parametrize("case", ["clean", "half_outliers", "all_fail_then_good", "perfect", "hopeless"])
 def test_ransac_replay_follows_the_reference_loop(case):
     """slam_ransac_replay (host only): the loop's bookkeeping over batches of precomputed hypotheses equals the
