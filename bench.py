@@ -784,7 +784,7 @@ def run_loops(args, rk: Rank):
             ev[1].record()
             keys = table.to(used_dev.device)[used_dev].contiguous()
             ev[2].record()
-        res = trk.run(*dev_args, f0, f1, seeds, unpack_mask=False, stereo_key=keys)
+        res = trk.run(*dev_args, f0, f1, seeds, unpack_mask=False, stereo_key=keys, copy=False)   # views: consumed before the next run
         if two:
             phase_ms.append((ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])))
         pose, stats = sdist.gather_shard_results(res.pose, res.stats, P_total)

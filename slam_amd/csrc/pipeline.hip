@@ -517,8 +517,10 @@ struct Lane {
         std::vector<uint8_t> fin;
         while (!active.empty()) {
             t_h0 = now_ms();
-            need.clear();
-            for (int p : active) need.push_back({rs[p].draws_hint(rp), p});
+            need.resize(active.size());
+            parallel_for((int)active.size(), 256, [&](int a, int e) {
+                for (int k = a; k < e; ++k) need[k] = {rs[active[k]].draws_hint(rp), active[k]};
+            });
             std::stable_sort(need.begin(), need.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first > y.first; });
             batches.clear();
             for (size_t a0 = 0; a0 < need.size();) {

@@ -110,8 +110,11 @@ int RansacReplay::draws_hint(const RansacParams &p) const {
     if (p.fixed_iterations > 0) {
         rem = (double)p.fixed_iterations - it;
     } else {
-        const double est = std::log(1.0 - p.prob) / std::log(1.0 - std::pow(1.0 - outliers_perc, 4.0));
-        rem = (est < p.max_iterations ? est : p.max_iterations) - it;
+        // a cached estimate at or above the cap for a ratio not above the current one (the estimate grows with the ratio)
+        // gives the same minimum without log / pow: pairs of unrelated frames, thousands per loop-closure pass
+        const bool capped = est_for > 0.0 && outliers_perc >= est_for && est * (1.0 - 1e-9) >= p.max_iterations;
+        const double e = capped ? p.max_iterations : std::log(1.0 - p.prob) / std::log(1.0 - std::pow(1.0 - outliers_perc, 4.0));
+        rem = (e < p.max_iterations ? e : p.max_iterations) - it;
     }
     if (!(rem > 1.0)) rem = 1.0;
     const double ok_rate = draws > 0 ? (double)it / (double)draws : 1.0;
