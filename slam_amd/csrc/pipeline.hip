@@ -150,7 +150,7 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
         b.poseR[k] = d.take<double>((size_t)HYP_BUDGET * 12);
         b.statusR[k] = d.take<uint8_t>(HYP_BUDGET);
         b.cntR[k] = d.take<int32_t>(HYP_BUDGET);
-        b.best_idxR[k] = d.take<int32_t>(b.RB);
+        b.best_idxR[k] = d.take<int32_t>(2 * (size_t)b.RB);      // a sub-batch's new winners | its rows' pairs
     }
 
     b.h_prob = h.take<int32_t>(3 * (Fs + Ps) + 3 * Ps);   // mirrors `setup`
@@ -162,7 +162,7 @@ void layout(int F, int P, int n_max, const SlamTrackConfig *cfg, Carver &d, Carv
         b.h_beginR[k] = h.take<int32_t>(b.RB);
         b.h_statusR[k] = h.take<uint8_t>(HYP_BUDGET);
         b.h_cntR[k] = h.take<int32_t>(HYP_BUDGET);
-        b.h_best_idxR[k] = h.take<int32_t>(b.RB);
+        b.h_best_idxR[k] = h.take<int32_t>(2 * (size_t)b.RB);
     }
     bind_blocks(b, Ps);
 }
@@ -305,6 +305,8 @@ struct Lane {
     hipEvent_t evR[2];                               // results of a later-round sub-batch have arrived (per slot)
     hipEvent_t evK[2];                               // kernels of a later-round sub-batch have finished (per slot)
     hipStream_t cs = nullptr;                        // copy stream: a sub-batch's results travel while the next one is evaluated
+    hipStream_t ds = nullptr;                        // draw stream: the next sub-batch's sample indices are generated meanwhile
+    hipEvent_t evD[2];                               // a later-round sub-batch's sample indices are there (per slot)
     hipEvent_t evA = nullptr;                        // round 0 has been downloaded
     hipEvent_t ev_matched = nullptr;                 // the chunk's matcher has finished
     hipEvent_t match_after = nullptr;                // event the chunk's matcher waits for (serial matchers), or null
@@ -330,6 +332,8 @@ struct Lane {
             for (auto &e : evR) SLAM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             for (auto &e : evK) SLAM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             SLAM_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            SLAM_HIP_CHECK(hipStreamCreateWithFlags(&ds, hipStreamNonBlocking));
+            for (auto &e : evD) SLAM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             SLAM_HIP_CHECK(hipEventCreateWithFlags(&evA, hipEventDisableTiming));
             SLAM_HIP_CHECK(hipEventCreateWithFlags(&ev_matched, hipEventDisableTiming));
             ev_ready = true;
@@ -548,10 +552,16 @@ struct Lane {
             // device: upload, solve, score, download; evR[s] marks the results' arrival
             auto launch = [&](const Batch &B, int s) -> int {
                 const int rows = B.rows, n_eval = B.n_eval;
-                SLAM_HIP_CHECK(hipMemcpyAsync(b.seg_of[s], b.h_seg_of[s], sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
-                SLAM_HIP_CHECK(hipMemcpyAsync(b.beginR[s], b.h_beginR[s], sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
-                int r2 = slam_launch_draw_samples(b.seed, b.tcount, b.seg_of[s], b.beginR[s], rows, n_eval, b.sampleR[s], nullptr, st);
+                // The sample indices are generated on the draw stream: one wavefront per pair regenerating its MT19937
+                // stream is a latency chain that fills a hundredth of the chip, and on `st` it would sit between the
+                // previous sub-batch's scoring and this one's AP3P (0.1 ms of every 0.8).  Here it runs under the previous
+                // sub-batch's kernels.  What it reads (seeds, point counts) was complete before round 0 was downloaded.
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.seg_of[s], b.h_seg_of[s], sizeof(int32_t) * rows, hipMemcpyHostToDevice, ds));
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.beginR[s], b.h_beginR[s], sizeof(int32_t) * rows, hipMemcpyHostToDevice, ds));
+                int r2 = slam_launch_draw_samples(b.seed, b.tcount, b.seg_of[s], b.beginR[s], rows, n_eval, b.sampleR[s], nullptr, ds);
                 if (r2) return r2;
+                SLAM_HIP_CHECK(hipEventRecord(evD[s], ds));
+                SLAM_HIP_CHECK(hipStreamWaitEvent(st, evD[s], 0));
                 r2 = slam_launch_p3p(sh.K, b.X, b.xy1, 0, b.tcount, b.seg_of[s], rows, N, b.sampleR[s], n_eval, 0, n_eval,
                                          b.poseR[s], b.statusR[s], st);
                 if (r2) return r2;
@@ -582,15 +592,18 @@ struct Lane {
                         q.consume(rp, b.h_tcount[p], b.h_statusR[s] + (size_t)r * n_eval, b.h_cntR[s] + (size_t)r * n_eval, begin,
                                   begin + n_eval);
                         b.h_best_idxR[s][r] = q.best_draw != before ? q.best_draw - begin : -1;
+                        b.h_best_idxR[s][rows + r] = p;
                         fin[r] = q.finished;
                     }
                 });
                 for (int r = 0; r < rows; ++r)
                     if (!fin[r]) still.push_back(need[B.a0 + r].second);
                 host_ms += now_ms() - t0;
-                SLAM_HIP_CHECK(hipMemcpyAsync(b.best_idxR[s], b.h_best_idxR[s], sizeof(int32_t) * rows, hipMemcpyHostToDevice, st));
+                // the gather takes its rows' pairs from its own upload, not from seg_of[s]: the draw stream may refill that
+                // array for the slot's next sub-batch before the gather, queued behind the other slot's kernels, has run
+                SLAM_HIP_CHECK(hipMemcpyAsync(b.best_idxR[s], b.h_best_idxR[s], sizeof(int32_t) * 2 * rows, hipMemcpyHostToDevice, st));
                 hipLaunchKernelGGL(gather_best_kernel, dim3(slam_div_up((long)rows * 12, 256)), dim3(256), 0, st, b.poseR[s],
-                                   b.statusR[s], b.best_idxR[s], b.seg_of[s], rows, n_eval, b.best_pose, b.best_status);
+                                   b.statusR[s], b.best_idxR[s], b.best_idxR[s] + rows, rows, n_eval, b.best_pose, b.best_status);
                 SLAM_HIP_CHECK(hipGetLastError());
                 return SLAM_OK;
             };
@@ -599,8 +612,10 @@ struct Lane {
             // slot reuse is safe by construction: a slot's host buffers are rewritten only after finish() of the
             // sub-batch that last used them (its uploads and results are done; its small best-index upload precedes, in
             // stream order, the launch whose completion finish() of the slot's next user waits for), and its device
-            // buffers only by work queued behind that sub-batch's gather on `st` -- queued by the host after finish()
-            // has seen the slot's copies on `cs` complete (evR).
+            // buffers only by work the host queues after finish() has seen the slot's copies on `cs` complete (evR: the
+            // sub-batch's kernels are done) -- on `st` behind that sub-batch's gather (poses, statuses, counts), on `ds`
+            // at once (pair list, draw ranges, sample indices: nothing queued still reads them, the gather has its own
+            // copy of the pair list).
             draw(batches[0], 0);
             rc = launch(batches[0], 0);
             if (rc) return rc;
@@ -697,8 +712,10 @@ struct ThreadState {
                 for (auto &e : ln.ev) (void)hipEventDestroy(e);
                 for (auto &e : ln.evR) (void)hipEventDestroy(e);
                 for (auto &e : ln.evK) (void)hipEventDestroy(e);
+                for (auto &e : ln.evD) (void)hipEventDestroy(e);
                 if (ln.cs) (void)hipStreamDestroy(ln.cs);
-                ln.cs = nullptr;
+                if (ln.ds) (void)hipStreamDestroy(ln.ds);
+                ln.cs = ln.ds = nullptr;
                 (void)hipEventDestroy(ln.evA);
                 (void)hipEventDestroy(ln.ev_matched);
                 ln.ev_ready = false;
@@ -719,7 +736,7 @@ struct ThreadState {
     }
     // drops the handles without destroying them (their device is unreachable)
     void forget() {
-        for (Lane &ln : lane) ln.ev_ready = false, ln.cs = nullptr;
+        for (Lane &ln : lane) ln.ev_ready = false, ln.cs = ln.ds = nullptr;
         fork = base = nullptr;
         for (auto &s : side_stream) s = nullptr;
         device = -1;
@@ -940,6 +957,7 @@ int track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *io, const uint32_
         if (rc) {
             (void)hipStreamSynchronize(st);                      // no work of a failed call outlives it
             if (L[0].cs) (void)hipStreamSynchronize(L[0].cs);
+            if (L[0].ds) (void)hipStreamSynchronize(L[0].ds);
             return rc;
         }
         n_launch = 1;
@@ -990,8 +1008,10 @@ int track_pairs(const SlamTrackConfig *cfg, const SlamTrackIO *io, const uint32_
             // the first error is the one reported; still drain both lanes so no work outlives the call
             (void)hipStreamSynchronize(g_ts.side_stream[0]);
             (void)hipStreamSynchronize(g_ts.side_stream[1]);
-            for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < 2; ++k) {
                 if (L[k].cs) (void)hipStreamSynchronize(L[k].cs);
+                if (L[k].ds) (void)hipStreamSynchronize(L[k].ds);
+            }
             return rc;
         }
         n_launch = C;
