@@ -721,18 +721,21 @@ __global__ __launch_bounds__(SB) __attribute__((amdgpu_waves_per_eu(SLAM_F32_WPE
                 a[u] = tile[2 * (i + u)];
                 b[u] = tile[2 * (i + u) + 1];
             }
-            unsigned und = 0;
+            // which lanes are undecided, per test, as wave masks in scalar registers (no per-lane bookkeeping in the scan)
+            unsigned long long und[PU_ * HL], any = 0ull;
 #pragma unroll
             for (int u = 0; u < PU_; ++u)
 #pragma unroll
                 for (int e = 0; e < HL; ++e) {
                     const int f = classify_f32(H[e], a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y, b[u].z, b[u].w, thrf);
                     total[e] += f & 1;
-                    und |= (f == 0 && live[e]) ? 1u << (u * HL + e) : 0u;
+                    und[u * HL + e] = __builtin_amdgcn_ballot_w64(f == 0 && live[e]);
+                    any |= und[u * HL + e];
                 }
-            if (__ballot(und != 0u)) {
+            if (any) {
+#pragma unroll
                 for (int t = 0; t < PU_ * HL; ++t)
-                    if (und >> t & 1u) {
+                    if (und[t] >> lane & 1ull) {
                         const int slot = atomicAdd(&wq_n[wave], 1);          // < WQCAP: drained below before it can fill
                         wq[wave][slot] = (unsigned)lane << 24 | (unsigned)(t % HL) << 16 | (unsigned)(base + i + t / HL);
                     }
